@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""bench.py -- ExSUM / ExDOT throughput on MI355X with inputs resident in HBM.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over the rank's synthetic vector(s): the streaming kernel, the
+finalize kernel and -- for N > 1 -- the 576-byte int64 all-reduce of the digit set (RCCL) plus the
+re-finalize.  Weak scaling: every rank holds n elements (default 2^28) of a global vector of N*n
+elements generated in place by the counter-based generator, so `value` = N*n*K / max-over-ranks time.
+
+Prints ONE JSON line on rank 0 (see README / task contract), with `roofline` for the dominant
+kernel (k_exsum resp. k_exdot: algorithmic 8 resp. 16 B/element over the HIP-event time of that
+kernel alone) and `cpu_baseline` (N == 1 only: the reference's own compiled FPE+superaccumulator
+core from oracle/_ref when it can be loaded, else our C port, on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--op", default="exsum", choices=["exsum", "exdot"])
+    ap.add_argument("--log2n", type=int, default=28, help="elements per GPU = 2^log2n")
+    ap.add_argument("--kind", default="ill_cond")
+    ap.add_argument("--p0", type=float, default=1e32)
+    ap.add_argument("--p1", type=float, default=0.0)
+    ap.add_argument("--fpe", type=int, default=8)
+    ap.add_argument("--no-early-exit", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary op (ExDOT) line items")
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "hbm_traffic.json"),
+                    help="per-launch HBM bytes from a separate rocprofv3 --pmc pass, if present")
+    return ap.parse_args()
+
+
+def timed_steps(ex, torch, dist, op, tensors, fpe, ee, steps, warmup, world, rec):
+    """Returns (wall seconds for `steps` steps, mean ms of the streaming kernel alone)."""
+    def one_step(e0=None, e1=None):
+        if e0 is not None:
+            e0.record()
+        if op == "exsum":
+            ex.exsum_accumulate_dev(tensors[0], fpe, ee)
+        else:
+            ex.exdot_accumulate_dev(tensors[0], tensors[1], fpe, ee)
+        if e1 is not None:
+            e1.record()
+        ex.finish_dev(out=rec)
+        if world > 1:
+            ex.allreduce_record(rec)
+            ex.finalize_dev(rec[ex.OUT_DIGITS:ex.OUT_DIGITS + ex.SET_WORDS], out=rec)
+
+    for _ in range(warmup):
+        one_step()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        one_step(*ev[i])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kms = sum(a.elapsed_time(b) for a, b in ev) / max(steps, 1)
+    return dt, kms
+
+
+def cpu_baseline(op, host_arrays, fpe, ee, limbs_gpu):
+    """Time the CPU path on this box's host cores, on the same vector(s); returns the JSON object."""
+    import numpy as np
+    from oracle import pyoracle as O
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    n = host_arrays[0].size
+    use_ref = op == "exsum" and O.ref() is not None
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    best = None
+    reps = 0
+    t_start = time.perf_counter()
+    limbs = None
+    while reps < 5 and (time.perf_counter() - t_start) < 25.0:
+        t0 = time.perf_counter()
+        if use_ref:
+            _, limbs = O.ref_exsum(host_arrays[0], fpe, ee, nthreads=cores, limbs=True)
+        elif op == "exsum":
+            _, limbs = O.exsum_omp(host_arrays[0], fpe, ee, cores, limbs=True)
+        else:
+            _, limbs = O.exdot_omp(host_arrays[0], host_arrays[1], fpe, ee, cores, limbs=True)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+        reps += 1
+    ok = bool((np.asarray(limbs) == np.asarray(limbs_gpu)).all())
+    impl = ("reference FPExpansionVect+Superaccumulator (oracle/_ref, -O1 -mavx2 -mfma) under our OpenMP slice driver"
+            if use_ref else "oracle/exblas_oracle.c OpenMP port")
+    return {
+        "value": n / best / 1e9, "unit": "Gelem/s", "cores": cores,
+        "kind": "reference" if use_ref else "port",
+        "sample": f"full workload, n={n}, {impl}, fpe={fpe} early_exit={ee}, best of {reps}",
+        "seconds": best,
+    }, ok
+
+
+def main():
+    args = parse()
+    import torch
+    import exblas_amd as ex
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    ex.load_library().exblas_hip_init(-1)
+
+    n = 1 << args.log2n
+    n_total = n * world
+    ee = not args.no_early_exit
+    first = rank * n
+    x = ex.gen_dev(args.kind, n, 1, args.p0, args.p1, first=first, count=n, n_total=n_total)
+    tensors = [x]
+    if args.op == "exdot":
+        tensors.append(ex.gen_dev(args.kind, n, 2, args.p0, args.p1, first=first, count=n, n_total=n_total))
+    rec = ex.new_record_buffer()
+    bytes_per_elem = 8 if args.op == "exsum" else 16
+
+    dt, kms = timed_steps(ex, torch, dist, args.op, tensors, args.fpe, ee, args.steps, args.warmup, world, rec)
+    if world > 1:
+        t = torch.tensor([dt, kms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt, kms = float(t[0]), float(t[1])
+    result = ex.read_record(rec)
+
+    # read-bandwidth probe of the box (plain streaming sum, same launch geometry)
+    sink = torch.zeros(1, dtype=torch.float64, device="cuda")
+    for _ in range(3):
+        ex.stream_read_dev(x, sink)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        ex.stream_read_dev(x, sink)
+    e1.record()
+    torch.cuda.synchronize()
+    probe_gbs = 10 * n * 8 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+    secondary = None
+    if not args.no_secondary and args.op == "exsum":
+        # ExDOT on the same shape (BASELINE config 2), reported beside the headline number
+        y = ex.gen_dev(args.kind, n, 2, args.p0, args.p1, first=first, count=n, n_total=n_total)
+        rec2 = ex.new_record_buffer()
+        ddt, dkms = timed_steps(ex, torch, dist, "exdot", [x, y], args.fpe, ee, args.steps, args.warmup, world, rec2)
+        if world > 1:
+            t = torch.tensor([ddt, dkms], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ddt, dkms = float(t[0]), float(t[1])
+        dach = n * 16 / (dkms * 1e-3) / 1e9
+        secondary = {"metric": "ExDOT fp64 Gelem/s", "value": n_total * args.steps / ddt / 1e9, "unit": "Gelem/s",
+                     "ms_per_step": ddt / args.steps * 1e3,
+                     "roofline": {"bound": "hbm", "achieved": dach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": dach / HBM_PEAK_GBS, "traffic": None, "kernel": "k_exdot",
+                                  "kernel_ms": dkms},
+                     "result": ex.read_record(rec2).exact}
+        del y
+
+    out = None
+    if rank == 0:
+        achieved = n * bytes_per_elem / (kms * 1e-3) / 1e9
+        traffic = None
+        if os.path.exists(args.traffic_json):
+            try:
+                traffic = json.load(open(args.traffic_json)).get(f"k_{args.op}")
+            except Exception:  # noqa: BLE001
+                traffic = None
+        out = {
+            "metric": f"Ex{args.op[2:].upper()} fp64 Gelem/s at n=2^{args.log2n} per GPU (bit-exact vs CPU superaccumulator/MPFR)",
+            "value": n_total * args.steps / dt / 1e9,
+            "unit": "Gelem/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": f"synthetic ({args.kind} p0={args.p0:g} p1={args.p1:g}, counter-based generator, seed 1)",
+            "config": {"workload": f"Ex{args.op[2:].upper()} n=2^{args.log2n} fp64 {args.kind}"
+                                   f"(c={args.p0:g}) per GPU, fpe={args.fpe} early_exit={ee}, "
+                                   f"{world}xMI355X, inputs resident in HBM",
+                       "elements_per_gpu": n, "fpe": args.fpe, "early_exit": ee,
+                       "parallelism": f"shard{world}" if world > 1 else "single"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": f"k_{args.op}", "kernel_ms": kms,
+                         "measured_read_probe_GBs": probe_gbs, "frac_of_probe": achieved / probe_gbs},
+            "result": result.exact,
+        }
+        if secondary:
+            out["exdot"] = secondary
+        if world == 1 and not args.no_cpu_baseline:
+            host = [t.cpu().numpy() for t in tensors]
+            base, ok = cpu_baseline(args.op, host, args.fpe, ee, result.canon)
+            out["cpu_baseline"] = base
+            out["bit_exact_vs_cpu"] = ok
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,428 @@
+// blas1.hip -- ExSUM / ExDOT for gfx950: streaming FPE front-end + per-wavefront LDS superaccumulators.
+//
+// Replaces the reference's OpenCL kernels ExSUM/ExSUMComplete (src/gpu/blas/blas1/ExSUM.Superacc.cl:211-356,
+// ExSUM.FPE.cl:230-388, ExSUM.FPE.EX.{4,6,8}.cl) and ExDOT/ExDOTComplete (ExDOT.Superacc.cl:217-359,
+// ExDOT.FPE.cl:201-345) -- behaviour only; the structure is ours:
+//   * every lane streams 16-byte (double2) coalesced, non-temporal loads, U of them in flight per tile;
+//   * a register-resident floating-point expansion of NFPE doubles absorbs the elements with Knuth
+//     TwoSum; the early-exit test is one wave-uniform branch per level per *tile* (not per element);
+//   * what survives the expansion is split by integer shifts and added with ds_add_u64 to a
+//     per-wavefront superaccumulator in LDS (COPIES columns per wave, limb-major, see superacc.hip.h);
+//   * block epilogue: merge the columns, add the non-zero limbs to one of NGROUPS global accumulators
+//     with int64 atomics (exact, order-free); the finalize kernel sums the groups, carry-propagates
+//     ONCE, re-cuts into the reference's canonical limbs and rounds.  No inter-workgroup reads inside a
+//     launch (the reference's ExSUMComplete races on that).
+#include "superacc.hip.h"
+#include "exblas_internal.h"
+
+namespace exb {
+
+typedef double d2_t __attribute__((ext_vector_type(2)));
+
+template <bool NT>
+__device__ __forceinline__ d2_t ld2(const d2_t *p)
+{
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+
+constexpr int BLOCK = 256;
+constexpr int WAVES = BLOCK / 64;
+
+// ---------------------------------------------------------------------------------------------
+// per-lane floating-point expansion
+// ---------------------------------------------------------------------------------------------
+template <int N, bool EE, int COPIES, int CNT>
+__device__ __forceinline__ void fpe_absorb(double (&a)[N > 0 ? N : 1], double (&x)[CNT], int from,
+                                           long long *col, unsigned &flags)
+{
+    if constexpr (N == 0) {
+#pragma unroll
+        for (int j = 0; j < CNT; ++j) lds_add<COPIES>(col, x[j], flags);
+    } else {
+        bool live = true;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            if (i >= from && live) {
+#pragma unroll
+                for (int j = 0; j < CNT; ++j) {
+                    double s;
+                    a[i] = two_sum(a[i], x[j], s);
+                    x[j] = s;
+                }
+                if (EE && i > from) {
+                    bool nz = false;
+#pragma unroll
+                    for (int j = 0; j < CNT; ++j) nz |= (x[j] != 0.0);
+                    live = __any(nz);  // wave-uniform
+                }
+            }
+        }
+        if (live) {
+            // residues of a non-finite element are NaN by-products: the lane's a[0] carries the
+            // IEEE class of its inputs (inf + finite = inf, inf - inf = NaN) and is classified at
+            // the final flush, so flags raised here are dropped
+            unsigned by_product = 0;
+#pragma unroll
+            for (int j = 0; j < CNT; ++j)
+                if (x[j] != 0.0) lds_add<COPIES>(col, x[j], by_product);
+        }
+    }
+}
+
+template <int N, int COPIES>
+__device__ __forceinline__ void fpe_flush(double (&a)[N > 0 ? N : 1], long long *col, unsigned &flags)
+{
+    if constexpr (N > 0) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            unsigned by_product = 0;
+            if (a[i] != 0.0) lds_add<COPIES>(col, a[i], i == 0 ? flags : by_product);
+            a[i] = 0.0;
+        }
+    }
+}
+
+// block epilogue: columns -> one limb vector -> global group accumulator
+template <int COPIES>
+__device__ __forceinline__ void block_epilogue(long long *s_acc, unsigned flags, long long *gacc,
+                                               unsigned *gflags, int ngroups)
+{
+    __shared__ unsigned s_flags;
+    if (threadIdx.x == 0) s_flags = 0;
+    __syncthreads();  // also orders every wave's LDS atomics before the merge
+    if (flags) atomicOr(&s_flags, flags);
+    long long *g = gacc + (size_t)(blockIdx.x % ngroups) * NL;
+    for (int l = threadIdx.x; l < NL; l += BLOCK) {
+        long long sum = 0;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w)
+#pragma unroll
+            for (int c = 0; c < COPIES; ++c) sum += s_acc[(w * NL + l) * COPIES + c];
+        if (sum != 0) atomicAdd((unsigned long long *)&g[l], (unsigned long long)sum);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_flags) atomicOr(gflags, s_flags);
+}
+
+// ---------------------------------------------------------------------------------------------
+// ExSUM, contiguous input
+// ---------------------------------------------------------------------------------------------
+template <int N, bool EE, int COPIES, int U, bool NT>
+__global__ void __launch_bounds__(BLOCK) k_exsum(const double *__restrict__ a, long long n,
+                                                 long long *__restrict__ gacc,
+                                                 unsigned *__restrict__ gflags, int ngroups)
+{
+    __shared__ long long s_acc[WAVES * NL * COPIES];
+    for (int i = threadIdx.x; i < WAVES * NL * COPIES; i += BLOCK) s_acc[i] = 0;
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    long long *col = s_acc + wave * NL * COPIES + (lane & (COPIES - 1));
+    unsigned flags = 0;
+    double fpe[N > 0 ? N : 1];
+#pragma unroll
+    for (int i = 0; i < (N > 0 ? N : 1); ++i) fpe[i] = 0.0;
+
+    // 16-byte alignment: at most one scalar head element
+    const long long head = (((uintptr_t)a & 8u) && n > 0) ? 1 : 0;
+    const d2_t *v = (const d2_t *)(a + head);
+    const long long nv = (n - head) >> 1;
+    constexpr long long TILE = (long long)BLOCK * U;
+    const long long ntiles = nv / TILE;
+
+    for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const d2_t *p = v + t * TILE + threadIdx.x;
+        d2_t r[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) r[u] = ld2<NT>(p + u * BLOCK);
+        double x[2 * U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            x[2 * u] = r[u].x;
+            x[2 * u + 1] = r[u].y;
+        }
+        fpe_absorb<N, EE, COPIES, 2 * U>(fpe, x, 0, col, flags);
+    }
+    // remainder vectors, grid-strided one double2 at a time
+    for (long long i = ntiles * TILE + (long long)blockIdx.x * BLOCK + threadIdx.x; i < nv;
+         i += (long long)gridDim.x * BLOCK) {
+        d2_t r = v[i];
+        double x[2] = {r.x, r.y};
+        fpe_absorb<N, false, COPIES, 2>(fpe, x, 0, col, flags);
+    }
+    // scalar head / tail straight into the superaccumulator
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (head) lds_add<COPIES>(col, a[0], flags);
+        if ((n - head) & 1) lds_add<COPIES>(col, a[n - 1], flags);
+    }
+    fpe_flush<N, COPIES>(fpe, col, flags);
+    block_epilogue<COPIES>(s_acc, flags, gacc, gflags, ngroups);
+}
+
+// ExSUM, strided input a[i*inca] (ExSUM.Superacc.cl:248-264 takes the same slow path)
+template <int N, bool EE, int COPIES>
+__global__ void __launch_bounds__(BLOCK) k_exsum_strided(const double *__restrict__ a, long long n,
+                                                         long long inca, long long *__restrict__ gacc,
+                                                         unsigned *__restrict__ gflags, int ngroups)
+{
+    __shared__ long long s_acc[WAVES * NL * COPIES];
+    for (int i = threadIdx.x; i < WAVES * NL * COPIES; i += BLOCK) s_acc[i] = 0;
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    long long *col = s_acc + wave * NL * COPIES + (lane & (COPIES - 1));
+    unsigned flags = 0;
+    double fpe[N > 0 ? N : 1];
+#pragma unroll
+    for (int i = 0; i < (N > 0 ? N : 1); ++i) fpe[i] = 0.0;
+    for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (long long)gridDim.x * BLOCK) {
+        double x[1] = {a[i * inca]};
+        fpe_absorb<N, false, COPIES, 1>(fpe, x, 0, col, flags);
+    }
+    fpe_flush<N, COPIES>(fpe, col, flags);
+    block_epilogue<COPIES>(s_acc, flags, gacc, gflags, ngroups);
+}
+
+// ---------------------------------------------------------------------------------------------
+// ExDOT: TwoProductFMA front-end (ExDOT.Superacc.cl:25-29, :244-253); the rounding error of the
+// product enters the expansion at slot max(N-3,0) like ExDOT.FPE.cl:254
+// ---------------------------------------------------------------------------------------------
+template <int N, bool EE, int COPIES, int U, bool NT>
+__global__ void __launch_bounds__(BLOCK) k_exdot(const double *__restrict__ a, const double *__restrict__ b,
+                                                 long long n, long long *__restrict__ gacc,
+                                                 unsigned *__restrict__ gflags, int ngroups)
+{
+    __shared__ long long s_acc[WAVES * NL * COPIES];
+    for (int i = threadIdx.x; i < WAVES * NL * COPIES; i += BLOCK) s_acc[i] = 0;
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    long long *col = s_acc + wave * NL * COPIES + (lane & (COPIES - 1));
+    unsigned flags = 0;
+    double fpe[N > 0 ? N : 1];
+#pragma unroll
+    for (int i = 0; i < (N > 0 ? N : 1); ++i) fpe[i] = 0.0;
+    constexpr int EFROM = (N >= 3) ? N - 3 : 0;
+
+    // vector path only when both streams are 16-byte aligned (host guarantees or falls to strided)
+    const d2_t *va = (const d2_t *)a, *vb = (const d2_t *)b;
+    const long long nv = n >> 1;
+    constexpr long long TILE = (long long)BLOCK * U;
+    const long long ntiles = nv / TILE;
+    for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const long long base = t * TILE + threadIdx.x;
+        d2_t ra[U], rb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            ra[u] = ld2<NT>(va + base + u * BLOCK);
+            rb[u] = ld2<NT>(vb + base + u * BLOCK);
+        }
+        double x[2 * U], e[2 * U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            x[2 * u] = two_prod_safe(ra[u].x, rb[u].x, e[2 * u]);
+            x[2 * u + 1] = two_prod_safe(ra[u].y, rb[u].y, e[2 * u + 1]);
+        }
+        fpe_absorb<N, EE, COPIES, 2 * U>(fpe, x, 0, col, flags);
+        fpe_absorb<N, EE, COPIES, 2 * U>(fpe, e, EFROM, col, flags);
+    }
+    for (long long i = ntiles * TILE + (long long)blockIdx.x * BLOCK + threadIdx.x; i < nv;
+         i += (long long)gridDim.x * BLOCK) {
+        d2_t ra = va[i], rb = vb[i];
+        double x[2], e[2];
+        x[0] = two_prod_safe(ra.x, rb.x, e[0]);
+        x[1] = two_prod_safe(ra.y, rb.y, e[1]);
+        fpe_absorb<N, false, COPIES, 2>(fpe, x, 0, col, flags);
+        fpe_absorb<N, false, COPIES, 2>(fpe, e, EFROM, col, flags);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && (n & 1)) {
+        double e, p = two_prod_safe(a[n - 1], b[n - 1], e);
+        lds_add<COPIES>(col, p, flags);
+        lds_add<COPIES>(col, e, flags);  // e == 0 when p overflowed (two_prod_safe)
+    }
+    fpe_flush<N, COPIES>(fpe, col, flags);
+    block_epilogue<COPIES>(s_acc, flags, gacc, gflags, ngroups);
+}
+
+template <int N, bool EE, int COPIES>
+__global__ void __launch_bounds__(BLOCK) k_exdot_strided(const double *__restrict__ a, long long inca,
+                                                         const double *__restrict__ b, long long incb,
+                                                         long long n, long long *__restrict__ gacc,
+                                                         unsigned *__restrict__ gflags, int ngroups)
+{
+    __shared__ long long s_acc[WAVES * NL * COPIES];
+    for (int i = threadIdx.x; i < WAVES * NL * COPIES; i += BLOCK) s_acc[i] = 0;
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    long long *col = s_acc + wave * NL * COPIES + (lane & (COPIES - 1));
+    unsigned flags = 0;
+    double fpe[N > 0 ? N : 1];
+#pragma unroll
+    for (int i = 0; i < (N > 0 ? N : 1); ++i) fpe[i] = 0.0;
+    constexpr int EFROM = (N >= 3) ? N - 3 : 0;
+    for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (long long)gridDim.x * BLOCK) {
+        double x[1], e[1];
+        x[0] = two_prod_safe(a[i * inca], b[i * incb], e[0]);
+        fpe_absorb<N, false, COPIES, 1>(fpe, x, 0, col, flags);
+        fpe_absorb<N, false, COPIES, 1>(fpe, e, EFROM, col, flags);
+    }
+    fpe_flush<N, COPIES>(fpe, col, flags);
+    block_epilogue<COPIES>(s_acc, flags, gacc, gflags, ngroups);
+}
+
+// ---------------------------------------------------------------------------------------------
+// finalize: sum `nsets` limb vectors, ONE carry propagation, canonical limbs, rounding.
+// zero_sets: the input is the context's group accumulators -> leave them zeroed for the next call.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(128) k_finalize(long long *sets, int nsets, int set_stride, unsigned *gflags,
+                                                  unsigned flags_or, int zero_sets, long long *out)
+{
+    __shared__ long long v[NL];
+    __shared__ unsigned s_fl;
+    const int t = threadIdx.x;
+    if (t == 0) {
+        unsigned flags = flags_or;
+        if (gflags) {
+            flags |= *gflags;
+            if (zero_sets) *gflags = 0;
+        }
+        if (set_stride >= SET_WORDS)  // record-style sets carry their own flag indicators
+            for (int g = 0; g < nsets; ++g)
+                for (int k = 0; k < 3; ++k)
+                    if (sets[(size_t)g * set_stride + NL + k] != 0) flags |= (1u << k);
+        s_fl = flags;
+    }
+    if (t < NL) {
+        long long s = 0;
+        for (int g = 0; g < nsets; ++g) {
+            s += sets[(size_t)g * set_stride + t];
+            if (zero_sets) sets[(size_t)g * set_stride + t] = 0;
+        }
+        v[t] = s;
+    }
+    __syncthreads();  // every input word is read before the first output word is written (out may alias sets)
+    if (t == 0) {
+        long long loc[NL];
+        for (int i = 0; i < NL; ++i) loc[i] = v[i];
+        finish_record(loc, s_fl, out);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+static inline int grid_for(const Ctx &c, long long work_items, long long per_block)
+{
+    long long want = (work_items + per_block - 1) / per_block;
+    long long cap = (long long)c.num_cu * c.blocks_per_cu;
+    if (want < 1) want = 1;
+    return (int)(want < cap ? want : cap);
+}
+
+template <int N, bool EE>
+static hipError_t launch_exsum(Ctx &c, const double *a, long long n, long long inca, hipStream_t st)
+{
+    constexpr int COPIES = (N == 0) ? 16 : 8;
+    constexpr int U = 4;
+    if (inca == 1) {
+        int grid = grid_for(c, n, (long long)BLOCK * 2 * U);
+        if (c.nontemporal)
+            hipLaunchKernelGGL((k_exsum<N, EE, COPIES, U, true>), dim3(grid), dim3(BLOCK), 0, st, a, n, c.gacc,
+                               c.gflags, c.ngroups);
+        else
+            hipLaunchKernelGGL((k_exsum<N, EE, COPIES, U, false>), dim3(grid), dim3(BLOCK), 0, st, a, n, c.gacc,
+                               c.gflags, c.ngroups);
+    } else {
+        int grid = grid_for(c, n, BLOCK);
+        hipLaunchKernelGGL((k_exsum_strided<N, EE, COPIES>), dim3(grid), dim3(BLOCK), 0, st, a, n, inca, c.gacc,
+                           c.gflags, c.ngroups);
+    }
+    return hipGetLastError();
+}
+
+template <int N, bool EE>
+static hipError_t launch_exdot(Ctx &c, const double *a, long long inca, const double *b, long long incb,
+                               long long n, hipStream_t st)
+{
+    constexpr int COPIES = (N == 0) ? 16 : 8;
+    constexpr int U = 2;
+    const bool vec = inca == 1 && incb == 1 && (((uintptr_t)a | (uintptr_t)b) & 15u) == 0;
+    if (vec) {
+        int grid = grid_for(c, n, (long long)BLOCK * 2 * U);
+        if (c.nontemporal)
+            hipLaunchKernelGGL((k_exdot<N, EE, COPIES, U, true>), dim3(grid), dim3(BLOCK), 0, st, a, b, n, c.gacc,
+                               c.gflags, c.ngroups);
+        else
+            hipLaunchKernelGGL((k_exdot<N, EE, COPIES, U, false>), dim3(grid), dim3(BLOCK), 0, st, a, b, n, c.gacc,
+                               c.gflags, c.ngroups);
+    } else {
+        int grid = grid_for(c, n, BLOCK);
+        hipLaunchKernelGGL((k_exdot_strided<N, EE, COPIES>), dim3(grid), dim3(BLOCK), 0, st, a, inca, b, incb, n,
+                           c.gacc, c.gflags, c.ngroups);
+    }
+    return hipGetLastError();
+}
+
+hipError_t finalize_groups(Ctx &c, hipStream_t st, long long *d_out)
+{
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(128), 0, st, c.gacc, c.ngroups, NL, c.gflags, 0u, 1, d_out);
+    return hipGetLastError();
+}
+
+hipError_t finalize_sets(const long long *d_sets, int nsets, unsigned flags_or, hipStream_t st, long long *d_out)
+{
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(128), 0, st, const_cast<long long *>(d_sets), nsets, SET_WORDS,
+                       (unsigned *)nullptr, flags_or, 0, d_out);
+    return hipGetLastError();
+}
+
+// variant selection: gpu:ExSUM.cpp:64-84 (fpe < 2 -> superaccumulators only; early_exit buckets 4/6/8)
+hipError_t exsum_dispatch(Ctx &c, const double *a, long long n, long long inca, int fpe, int early_exit,
+                          hipStream_t st, bool *supported)
+{
+    *supported = true;
+    if (fpe < 2) return launch_exsum<0, false>(c, a, n, inca, st);
+    if (early_exit) {
+        if (fpe <= 4) return launch_exsum<4, true>(c, a, n, inca, st);
+        if (fpe <= 6) return launch_exsum<6, true>(c, a, n, inca, st);
+        if (fpe <= 8) return launch_exsum<8, true>(c, a, n, inca, st);
+    } else {
+        switch (fpe) {
+        case 2: return launch_exsum<2, false>(c, a, n, inca, st);
+        case 3: return launch_exsum<3, false>(c, a, n, inca, st);
+        case 4: return launch_exsum<4, false>(c, a, n, inca, st);
+        case 5: return launch_exsum<5, false>(c, a, n, inca, st);
+        case 6: return launch_exsum<6, false>(c, a, n, inca, st);
+        case 7: return launch_exsum<7, false>(c, a, n, inca, st);
+        case 8: return launch_exsum<8, false>(c, a, n, inca, st);
+        default: break;
+        }
+    }
+    *supported = false;  // the reference silently returns 0.0 (gpu:ExSUM.cpp:83)
+    return hipSuccess;
+}
+
+// ExDOT.cpp:69-98 (fpe < 3 -> superaccumulators only)
+hipError_t exdot_dispatch(Ctx &c, const double *a, long long inca, const double *b, long long incb, long long n,
+                          int fpe, int early_exit, hipStream_t st, bool *supported)
+{
+    *supported = true;
+    if (fpe < 3) return launch_exdot<0, false>(c, a, inca, b, incb, n, st);
+    if (early_exit) {
+        if (fpe <= 4) return launch_exdot<4, true>(c, a, inca, b, incb, n, st);
+        if (fpe <= 6) return launch_exdot<6, true>(c, a, inca, b, incb, n, st);
+        if (fpe <= 8) return launch_exdot<8, true>(c, a, inca, b, incb, n, st);
+    } else {
+        switch (fpe) {
+        case 3: return launch_exdot<3, false>(c, a, inca, b, incb, n, st);
+        case 4: return launch_exdot<4, false>(c, a, inca, b, incb, n, st);
+        case 5: return launch_exdot<5, false>(c, a, inca, b, incb, n, st);
+        case 6: return launch_exdot<6, false>(c, a, inca, b, incb, n, st);
+        case 7: return launch_exdot<7, false>(c, a, inca, b, incb, n, st);
+        case 8: return launch_exdot<8, false>(c, a, inca, b, incb, n, st);
+        default: break;
+        }
+    }
+    *supported = false;
+    return hipSuccess;
+}
+
+}  // namespace exb

@@ -1,0 +1,542 @@
+// capi.hip -- context, generators and the C ABI / C++ API of libexblas.so (see include/exblas_hip.h).
+//
+// The C++ functions exsum/exdot/exgemv/exgemm at the bottom carry the exact signatures of the
+// reference's public headers (include/blas1.hpp:48,74; blas2.hpp:57,95; blas3.hpp:56) and replace
+// src/gpu/blas/blas{1,2,3}/Ex*.cpp: same argument meaning, same variant dispatch, same error
+// behaviour (print + exit on fpe < 0 or device failure, 0.0 for Ng <= 0 / unsupported variants).
+#include "../../include/exblas_hip.h"
+#include "../../include/blas1.hpp"
+#include "../../include/blas2.hpp"
+#include "../../include/blas3.hpp"
+#include "exblas_internal.h"
+#include "superacc.hip.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+namespace exb {
+
+static_assert(OUT_WORDS == EXBLAS_OUT_WORDS && OUT_CANON == EXBLAS_OUT_CANON && OUT_DIGITS == EXBLAS_OUT_DIGITS &&
+                  NL == EXBLAS_NDIGITS && SET_WORDS == EXBLAS_SET_WORDS && CANON == EXBLAS_NCANON && OUT_EXACT == EXBLAS_OUT_EXACT &&
+                  OUT_REFMODE == EXBLAS_OUT_REFMODE && OUT_FLAGS == EXBLAS_OUT_FLAGS,
+              "record layout out of sync with include/exblas_hip.h");
+
+[[noreturn]] void die(const char *what, hipError_t e, const char *file, int line)
+{
+    // the reference prints and exit(EXIT_FAILURE)s on any backend failure (gpu:ExSUM.cpp:111-115)
+    fprintf(stderr, "exblas(hip): %s failed: %s (%s:%d)\n", what, hipGetErrorString(e), file, line);
+    exit(EXIT_FAILURE);
+}
+
+static int env_int(const char *name, int dflt)
+{
+    const char *s = getenv(name);
+    return (s && *s) ? atoi(s) : dflt;
+}
+
+static int g_round_mode = -1;
+int round_mode()
+{
+    if (g_round_mode < 0) {
+        const char *s = getenv("EXBLAS_ROUND");
+        g_round_mode = (s && (s[0] == 'r' || s[0] == 'R' || s[0] == '1')) ? 1 : 0;
+    }
+    return g_round_mode;
+}
+
+static constexpr int MAX_DEV = 16;
+static Ctx g_ctx[MAX_DEV];
+static std::mutex g_ctx_mu;
+
+Ctx &ctx(int device)
+{
+    if (device < 0) {
+        hipError_t e = hipGetDevice(&device);
+        if (e != hipSuccess) {
+            // no usable HIP device: the product path refuses to run (there is no CPU fallback)
+            fprintf(stderr, "exblas(hip): no HIP device available: %s\n", hipGetErrorString(e));
+            exit(EXIT_FAILURE);
+        }
+    }
+    if (device >= MAX_DEV) {
+        fprintf(stderr, "exblas(hip): device index %d out of range\n", device);
+        exit(EXIT_FAILURE);
+    }
+    Ctx &c = g_ctx[device];
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    if (c.device < 0) {
+        int prev = 0;
+        EXB_CHECK(hipGetDevice(&prev));
+        EXB_CHECK(hipSetDevice(device));
+        hipDeviceProp_t prop;
+        EXB_CHECK(hipGetDeviceProperties(&prop, device));
+        c.num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        c.blocks_per_cu = env_int("EXBLAS_BLOCKS_PER_CU", 8);
+        c.ngroups = env_int("EXBLAS_NGROUPS", 32);
+        if (c.ngroups < 1) c.ngroups = 1;
+        c.nontemporal = env_int("EXBLAS_NT", 1) != 0;
+        EXB_CHECK(hipMalloc(&c.gacc, sizeof(long long) * NL * c.ngroups));
+        EXB_CHECK(hipMemset(c.gacc, 0, sizeof(long long) * NL * c.ngroups));
+        EXB_CHECK(hipMalloc(&c.gflags, 64));
+        EXB_CHECK(hipMemset(c.gflags, 0, 64));
+        EXB_CHECK(hipMalloc(&c.d_record, sizeof(long long) * OUT_WORDS));
+        EXB_CHECK(hipHostMalloc(&c.h_record, sizeof(long long) * OUT_WORDS));
+        EXB_CHECK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+        EXB_CHECK(hipDeviceSynchronize());
+        EXB_CHECK(hipSetDevice(prev));
+        c.device = device;
+    }
+    return c;
+}
+
+void *stage_buf(Ctx &c, int slot, size_t bytes)
+{
+    if (bytes > c.stage_bytes[slot]) {
+        if (c.stage[slot]) EXB_CHECK(hipFree(c.stage[slot]));
+        size_t cap = bytes + (bytes >> 3) + 4096;
+        EXB_CHECK(hipMalloc(&c.stage[slot], cap));
+        c.stage_bytes[slot] = cap;
+    }
+    return c.stage[slot];
+}
+
+void *workspace(Ctx &c, size_t bytes)
+{
+    if (bytes > c.ws_bytes) {
+        if (c.ws) EXB_CHECK(hipFree(c.ws));
+        EXB_CHECK(hipMalloc(&c.ws, bytes));
+        c.ws_bytes = bytes;
+    }
+    return c.ws;
+}
+
+// ---------------------------------------------------------------------------------------------
+// counter-based generators: the device twin of oracle/exblas_oracle.c:orc_gen_one (integer math,
+// exact conversions and power-of-two scalings only, so the bits are identical on CPU and GPU)
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ inline unsigned long long mix64(unsigned long long z)
+{
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ inline unsigned long long rnd(unsigned long long seed, unsigned long long i, unsigned long long k)
+{
+    return mix64(seed * 0xD1342543DE82EF95ull + (2 * i + k + 1) * 0x9E3779B97F4A7C15ull);
+}
+__device__ inline double pow2i(int e) { return __longlong_as_double((long long)(e + 1023) << 52); }
+__device__ inline double mant12(unsigned long long r)
+{
+    return __longlong_as_double((long long)(0x3FF0000000000000ull | (r >> 12)));
+}
+__device__ inline double mant_signed(unsigned long long r)
+{
+    long long k = (long long)(r >> 11);
+    return (double)(2 * k - (1ll << 53)) * 0x1p-53;
+}
+__device__ inline unsigned uni(unsigned long long r, unsigned range)
+{
+    return (unsigned)(((r >> 32) * (unsigned long long)range) >> 32);
+}
+
+__global__ void __launch_bounds__(256) k_gen(int kind, unsigned long long seed, long long first, long long count,
+                                             long long n, int i0, int i1, double dscale, double *out)
+{
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < count;
+         t += (long long)gridDim.x * blockDim.x) {
+        const long long i = first + t;
+        const unsigned long long r0 = rnd(seed, (unsigned long long)i, 0), r1 = rnd(seed, (unsigned long long)i, 1);
+        double v = 0.0;
+        switch (kind) {
+        case EXBLAS_GEN_NAIVE: v = 1.1; break;
+        case EXBLAS_GEN_FPUNIFORM:
+        case EXBLAS_GEN_FPUNIFORM_SIGNED: {
+            int e = i1 - i0 + (i0 > 0 ? (int)uni(r1, (unsigned)i0) : 0);
+            v = mant12(r0) * pow2i(e);
+            if (kind == EXBLAS_GEN_FPUNIFORM_SIGNED && (r1 & 1)) v = -v;
+            break;
+        }
+        case EXBLAS_GEN_LOGNORMAL: {
+            long long z = (long long)(r1 & 0xffff) + (long long)((r1 >> 16) & 0xffff) +
+                          (long long)((r1 >> 32) & 0xffff) + (long long)((r1 >> 48) & 0xffff) - 2 * 65535;
+            int e = (int)rint((double)z * dscale) + i0;
+            e = e > 1000 ? 1000 : (e < -1000 ? -1000 : e);
+            v = mant12(r0) * pow2i(e);
+            break;
+        }
+        case EXBLAS_GEN_ILLCOND: {
+            const int bh = i0;
+            const long long n2 = n / 2;
+            int e;
+            if (i < n2) e = (i == 0) ? bh + 1 : (int)uni(r1, (unsigned)(bh + 1));
+            else e = (n - n2 > 0) ? (int)(((i - n2) * (long long)bh) / (n - n2)) : 0;
+            v = mant_signed(r0) * pow2i(e);
+            break;
+        }
+        case EXBLAS_GEN_CANCEL: {
+            const long long h = n / 2;
+            if (i >= 2 * h) v = 0.0;
+            else if (i == h - 1) v = 1.0;
+            else if (i == 2 * h - 1) v = 0x1p-60;
+            else {
+                const long long j = (i < h) ? i : i - h;
+                const unsigned long long q0 = rnd(seed, (unsigned long long)j, 0),
+                                         q1 = rnd(seed, (unsigned long long)j, 1);
+                double w = mant_signed(q0) * pow2i(i0 > 0 ? (int)uni(q1, (unsigned)i0) : 0);
+                v = (i < h) ? w : -w;
+            }
+            break;
+        }
+        default: break;
+        }
+        out[t] = v;
+    }
+}
+
+// plain (inexact) streaming sum: read-bandwidth probe
+typedef double d2_t __attribute__((ext_vector_type(2)));
+__global__ void __launch_bounds__(256) k_stream_read(const double *a, long long n, double *sink)
+{
+    const d2_t *v = (const d2_t *)a;
+    const long long nv = n >> 1;
+    double s0 = 0, s1 = 0;
+    constexpr int U = 4;
+    const long long tile = 256ll * U, ntiles = nv / tile;
+    for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const d2_t *p = v + t * tile + threadIdx.x;
+        d2_t r[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) r[u] = __builtin_nontemporal_load(p + u * 256);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            s0 += r[u].x;
+            s1 += r[u].y;
+        }
+    }
+    if (s0 + s1 == 0x1.23456789abcdep-333) *sink = s0;  // keeps the loads alive, never true in practice
+}
+
+}  // namespace exb
+
+using namespace exb;
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" {
+
+int exblas_hip_init(int device)
+{
+    ctx(device);
+    return 0;
+}
+
+int exblas_hip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *exblas_hip_version(void) { return "exblas-hip 0.1 (gfx950)"; }
+
+void exblas_set_round_mode(int mode) { g_round_mode = mode ? 1 : 0; }
+int exblas_get_round_mode(void) { return round_mode(); }
+
+int exblas_exsum_accumulate_dev(const double *d_a, int64_t n, int64_t inca, int fpe, int early_exit, void *stream)
+{
+    if (fpe < 0) return (int)hipErrorInvalidValue;
+    Ctx &c = ctx(-1);
+    std::lock_guard<std::mutex> lk(c.mu);
+    bool ok = true;
+    // unsupported (fpe, early_exit) combination: nothing is launched, the accumulators stay zero -> 0.0
+    return n > 0 ? (int)exsum_dispatch(c, d_a, n, inca, fpe, early_exit, (hipStream_t)stream, &ok) : 0;
+}
+
+int exblas_exdot_accumulate_dev(const double *d_a, int64_t inca, const double *d_b, int64_t incb, int64_t n, int fpe,
+                                int early_exit, void *stream)
+{
+    if (fpe < 0) return (int)hipErrorInvalidValue;
+    Ctx &c = ctx(-1);
+    std::lock_guard<std::mutex> lk(c.mu);
+    bool ok = true;
+    return n > 0 ? (int)exdot_dispatch(c, d_a, inca, d_b, incb, n, fpe, early_exit, (hipStream_t)stream, &ok) : 0;
+}
+
+int exblas_finish_dev(void *stream, int64_t *d_out)
+{
+    Ctx &c = ctx(-1);
+    std::lock_guard<std::mutex> lk(c.mu);
+    return (int)finalize_groups(c, (hipStream_t)stream, (long long *)d_out);
+}
+
+int exblas_exsum_dev(const double *d_a, int64_t n, int64_t inca, int fpe, int early_exit, void *stream,
+                     int64_t *d_out)
+{
+    int rc = exblas_exsum_accumulate_dev(d_a, n, inca, fpe, early_exit, stream);
+    return rc ? rc : exblas_finish_dev(stream, d_out);
+}
+
+int exblas_exdot_dev(const double *d_a, int64_t inca, const double *d_b, int64_t incb, int64_t n, int fpe,
+                     int early_exit, void *stream, int64_t *d_out)
+{
+    int rc = exblas_exdot_accumulate_dev(d_a, inca, d_b, incb, n, fpe, early_exit, stream);
+    return rc ? rc : exblas_finish_dev(stream, d_out);
+}
+
+int exblas_finalize_dev(const int64_t *d_digit_sets, int nsets, uint32_t flags_or, void *stream, int64_t *d_out)
+{
+    ctx(-1);
+    return (int)finalize_sets((const long long *)d_digit_sets, nsets, flags_or, (hipStream_t)stream,
+                              (long long *)d_out);
+}
+
+int exblas_exgemv_dev(char transa, int m, int n, double alpha, const double *d_a, int lda, const double *d_x,
+                      int incx, double beta, double *d_y, int incy, int fpe, int early_exit, void *stream)
+{
+    if (fpe < 0) return (int)hipErrorInvalidValue;
+    Ctx &c = ctx(-1);
+    std::lock_guard<std::mutex> lk(c.mu);
+    return (int)exgemv_dispatch(c, transa, m, n, alpha, d_a, lda, d_x, incx, beta, d_y, incy, fpe, early_exit,
+                                round_mode(), (hipStream_t)stream);
+}
+
+int exblas_exgemm_dev(char transa, char transb, int m, int n, int k, double alpha, const double *d_a, int lda,
+                      const double *d_b, int ldb, double beta, double *d_c, int ldc, int fpe, int early_exit,
+                      void *stream)
+{
+    if (fpe < 0) return (int)hipErrorInvalidValue;
+    Ctx &c = ctx(-1);
+    std::lock_guard<std::mutex> lk(c.mu);
+    return (int)exgemm_dispatch(c, transa, transb, m, n, k, alpha, d_a, lda, d_b, ldb, beta, d_c, ldc, fpe,
+                                early_exit, round_mode(), (hipStream_t)stream);
+}
+
+int exblas_gen_dev(int kind, uint64_t seed, int64_t first, int64_t count, int64_t n_total, double p0, double p1,
+                   double *d_out, void *stream)
+{
+    Ctx &c = ctx(-1);
+    if (count <= 0) return 0;
+    int i0 = 0, i1 = 0;
+    double dscale = 0.0;
+    switch (kind) {
+    case EXBLAS_GEN_FPUNIFORM:
+    case EXBLAS_GEN_FPUNIFORM_SIGNED: i0 = (int)p0; i1 = (int)p1; break;
+    case EXBLAS_GEN_LOGNORMAL:
+        // same expressions as orc_gen_one, evaluated on the host in IEEE double
+        dscale = p1 * (1.0 / (0.6931471805599453 * 37837.22690659431));
+        i0 = (int)rint(p0 * (1.0 / 0.6931471805599453));
+        break;
+    case EXBLAS_GEN_ILLCOND: i0 = (int)rint(log2(p0) * 0.5); break;
+    case EXBLAS_GEN_CANCEL: i0 = (int)p0; break;
+    default: break;
+    }
+    long long blocks = (count + 255) / 256;
+    long long cap = (long long)c.num_cu * 16;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(k_gen, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, kind,
+                       (unsigned long long)seed, (long long)first, (long long)count, (long long)n_total, i0, i1,
+                       dscale, d_out);
+    return (int)hipGetLastError();
+}
+
+int exblas_stream_read_dev(const double *d_a, int64_t n, void *stream, double *d_sink)
+{
+    Ctx &c = ctx(-1);
+    long long blocks = (long long)c.num_cu * c.blocks_per_cu;
+    hipLaunchKernelGGL(k_stream_read, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_a, (long long)n,
+                       d_sink);
+    return (int)hipGetLastError();
+}
+
+// ---- host-pointer layer ---------------------------------------------------------------------
+
+static void check_fpe(int fpe)
+{
+    if (fpe < 0) {
+        // cpu:ExSUM.cpp:25-28
+        fprintf(stderr, "Size of floating-point expansion should be a positive number. Preferably, it should be "
+                        "in the interval [2, 8]\n");
+        exit(1);
+    }
+}
+
+int exblas_exsum_record(int Ng, const double *ag, int inca, int offset, int fpe, int early_exit,
+                        int64_t *out_words)
+{
+    check_fpe(fpe);
+    Ctx &c = ctx(-1);
+    const double *d_a = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(c.mu);
+        if (Ng > 0) {
+            // element count semantics of the GPU backend: a[offset + i*inca], i < Ng
+            // (ExSUM.Superacc.cl:249-250); the whole touched span is copied like gpu:ExSUM.cpp:126
+            size_t span = (size_t)(Ng - 1) * (size_t)(inca > 0 ? inca : 1) + 1;
+            double *buf = (double *)stage_buf(c, 0, span * sizeof(double));
+            EXB_CHECK(hipMemcpyAsync(buf, ag + offset, span * sizeof(double), hipMemcpyHostToDevice, c.stream));
+            d_a = buf;
+        }
+    }
+    int rc = exblas_exsum_dev(d_a, Ng > 0 ? Ng : 0, inca > 0 ? inca : 1, fpe, early_exit, c.stream,
+                              (int64_t *)c.d_record);
+    if (rc) die("exblas_exsum_dev", (hipError_t)rc, __FILE__, __LINE__);
+    EXB_CHECK(hipMemcpyAsync(c.h_record, c.d_record, sizeof(long long) * OUT_WORDS, hipMemcpyDeviceToHost,
+                             c.stream));
+    EXB_CHECK(hipStreamSynchronize(c.stream));
+    memcpy(out_words, c.h_record, sizeof(long long) * OUT_WORDS);
+    return 0;
+}
+
+int exblas_exdot_record(int Ng, const double *ag, int inca, int offseta, const double *bg, int incb, int offsetb,
+                        int fpe, int early_exit, int64_t *out_words)
+{
+    check_fpe(fpe);
+    Ctx &c = ctx(-1);
+    const double *d_a = nullptr, *d_b = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(c.mu);
+        if (Ng > 0) {
+            size_t spa = (size_t)(Ng - 1) * (size_t)(inca > 0 ? inca : 1) + 1;
+            size_t spb = (size_t)(Ng - 1) * (size_t)(incb > 0 ? incb : 1) + 1;
+            double *ba = (double *)stage_buf(c, 0, spa * sizeof(double));
+            double *bb = (double *)stage_buf(c, 1, spb * sizeof(double));
+            EXB_CHECK(hipMemcpyAsync(ba, ag + offseta, spa * sizeof(double), hipMemcpyHostToDevice, c.stream));
+            EXB_CHECK(hipMemcpyAsync(bb, bg + offsetb, spb * sizeof(double), hipMemcpyHostToDevice, c.stream));
+            d_a = ba;
+            d_b = bb;
+        }
+    }
+    int rc = exblas_exdot_dev(d_a, inca > 0 ? inca : 1, d_b, incb > 0 ? incb : 1, Ng > 0 ? Ng : 0, fpe, early_exit,
+                              c.stream, (int64_t *)c.d_record);
+    if (rc) die("exblas_exdot_dev", (hipError_t)rc, __FILE__, __LINE__);
+    EXB_CHECK(hipMemcpyAsync(c.h_record, c.d_record, sizeof(long long) * OUT_WORDS, hipMemcpyDeviceToHost,
+                             c.stream));
+    EXB_CHECK(hipStreamSynchronize(c.stream));
+    memcpy(out_words, c.h_record, sizeof(long long) * OUT_WORDS);
+    return 0;
+}
+
+static double record_value(const int64_t *rec)
+{
+    double d;
+    memcpy(&d, &rec[round_mode() ? EXBLAS_OUT_REFMODE : EXBLAS_OUT_EXACT], sizeof(d));
+    return d;
+}
+
+double exblas_exsum(int Ng, const double *ag, int inca, int offset, int fpe, int early_exit)
+{
+    int64_t rec[EXBLAS_OUT_WORDS];
+    exblas_exsum_record(Ng, ag, inca, offset, fpe, early_exit, rec);
+    return record_value(rec);
+}
+
+double exblas_exdot(int Ng, const double *ag, int inca, int offseta, const double *bg, int incb, int offsetb,
+                    int fpe, int early_exit)
+{
+    if (Ng <= 0) return 0.0;  // ExDOT.cpp:70-71
+    int64_t rec[EXBLAS_OUT_WORDS];
+    exblas_exdot_record(Ng, ag, inca, offseta, bg, incb, offsetb, fpe, early_exit, rec);
+    return record_value(rec);
+}
+
+int exblas_exgemv(char transa, int m, int n, double alpha, const double *a, int lda, int offseta, const double *x,
+                  int incx, int offsetx, double beta, double *y, int incy, int offsety, int fpe, int early_exit)
+{
+    check_fpe(fpe);
+    if (m <= 0 || n <= 0) return 0;
+    Ctx &c = ctx(-1);
+    const bool trans = (transa == 'T' || transa == 't');
+    const int rows = trans ? n : m, inner = trans ? m : n;
+    double *d_a, *d_x, *d_y;
+    size_t abytes = (size_t)lda * (size_t)n * sizeof(double);  // column-major: n columns of lda
+    size_t xspan = (size_t)(inner - 1) * (size_t)incx + 1, yspan = (size_t)(rows - 1) * (size_t)incy + 1;
+    {
+        std::lock_guard<std::mutex> lk(c.mu);
+        d_a = (double *)stage_buf(c, 0, abytes);
+        d_x = (double *)stage_buf(c, 1, xspan * sizeof(double));
+        d_y = (double *)stage_buf(c, 2, yspan * sizeof(double));
+        EXB_CHECK(hipMemcpyAsync(d_a, a + offseta, abytes - (size_t)(lda - m) * sizeof(double), hipMemcpyHostToDevice,
+                                 c.stream));
+        EXB_CHECK(hipMemcpyAsync(d_x, x + offsetx, xspan * sizeof(double), hipMemcpyHostToDevice, c.stream));
+        EXB_CHECK(hipMemcpyAsync(d_y, y + offsety, yspan * sizeof(double), hipMemcpyHostToDevice, c.stream));
+    }
+    int rc = exblas_exgemv_dev(transa, m, n, alpha, d_a, lda, d_x, incx, beta, d_y, incy, fpe, early_exit, c.stream);
+    if (rc) die("exblas_exgemv_dev", (hipError_t)rc, __FILE__, __LINE__);
+    EXB_CHECK(hipMemcpyAsync(y + offsety, d_y, yspan * sizeof(double), hipMemcpyDeviceToHost, c.stream));
+    EXB_CHECK(hipStreamSynchronize(c.stream));
+    return 0;
+}
+
+int exblas_exgemm(char transa, char transb, int m, int n, int k, double alpha, const double *a, int lda,
+                  const double *b, int ldb, double beta, double *cm, int ldc, int fpe, int early_exit)
+{
+    check_fpe(fpe);
+    if (m <= 0 || n <= 0) return 0;
+    Ctx &c = ctx(-1);
+    const bool ta = (transa == 'T' || transa == 't'), tb = (transb == 'T' || transb == 't');
+    // row-major storage (ExGEMM.Superacc.cl:254-255): A is m x k (k x m when transposed), etc.
+    size_t abytes = (size_t)(ta ? k : m) * (size_t)lda * sizeof(double);
+    size_t bbytes = (size_t)(tb ? n : k) * (size_t)ldb * sizeof(double);
+    size_t cbytes = (size_t)m * (size_t)ldc * sizeof(double);
+    double *d_a, *d_b, *d_c;
+    {
+        std::lock_guard<std::mutex> lk(c.mu);
+        d_a = (double *)stage_buf(c, 0, abytes);
+        d_b = (double *)stage_buf(c, 1, bbytes);
+        d_c = (double *)stage_buf(c, 2, cbytes);
+        EXB_CHECK(hipMemcpyAsync(d_a, a, abytes, hipMemcpyHostToDevice, c.stream));
+        EXB_CHECK(hipMemcpyAsync(d_b, b, bbytes, hipMemcpyHostToDevice, c.stream));
+        EXB_CHECK(hipMemcpyAsync(d_c, cm, cbytes, hipMemcpyHostToDevice, c.stream));
+    }
+    int rc = exblas_exgemm_dev(transa, transb, m, n, k, alpha, d_a, lda, d_b, ldb, beta, d_c, ldc, fpe, early_exit,
+                               c.stream);
+    if (rc) die("exblas_exgemm_dev", (hipError_t)rc, __FILE__, __LINE__);
+    EXB_CHECK(hipMemcpyAsync(cm, d_c, cbytes, hipMemcpyDeviceToHost, c.stream));
+    EXB_CHECK(hipStreamSynchronize(c.stream));
+    return 0;
+}
+
+}  // extern "C"
+
+// =============================================================================================
+// C++ API with the reference's signatures (global namespace, C++ linkage)
+// =============================================================================================
+double exsum(const int Ng, double *ag, const int inca, const int offset, const int fpe, const bool early_exit,
+             const bool parallel)
+{
+    (void)parallel;  // "Does not affect GPU implementation since it is always parallel" (gpu:ExSUM.cpp:61)
+    return exblas_exsum(Ng, ag, inca, offset, fpe, early_exit ? 1 : 0);
+}
+
+double exdot(const int Ng, double *ag, const int inca, const int offseta, double *bg, const int incb,
+             const int offsetb, const int fpe, const bool early_exit)
+{
+    return exblas_exdot(Ng, ag, inca, offseta, bg, incb, offsetb, fpe, early_exit ? 1 : 0);
+}
+
+int exgemv(const char transa, const int m, const int n, const double alpha, double *a, const int lda,
+           const int offseta, double *x, const int incx, const int offsetx, const double beta, double *y,
+           const int incy, const int offsety, const int fpe, const bool early_exit)
+{
+    return exblas_exgemv(transa, m, n, alpha, a, lda, offseta, x, incx, offsetx, beta, y, incy, offsety, fpe,
+                         early_exit ? 1 : 0);
+}
+
+int extrsv(const char uplo, const char transa, const char diag, const int n, double *a, const int lda,
+           const int offseta, double *x, const int incx, const int offsetx, const int fpe, const bool early_exit)
+{
+    // declared for link compatibility (blas2.hpp:57); the triangular solve is outside the reduction hot path
+    (void)uplo; (void)transa; (void)diag; (void)n; (void)a; (void)lda; (void)offseta; (void)x; (void)incx;
+    (void)offsetx; (void)fpe; (void)early_exit;
+    fprintf(stderr, "exblas(hip): extrsv is not implemented by this backend\n");
+    return -1;
+}
+
+int exgemm(char transa, char transb, int m, int n, int k, double alpha, double *a, int lda, double *b, int ldb,
+           double beta, double *c, int ldc, int fpe, bool early_exit)
+{
+    return exblas_exgemm(transa, transb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, fpe, early_exit ? 1 : 0);
+}

@@ -1,0 +1,61 @@
+// exblas_internal.h -- per-device context and cross-file declarations of libexblas.so
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <mutex>
+
+namespace exb {
+
+// Lazily created, one per device.  Replaces the file-static kernel/buffer globals of the reference
+// launchers (ExSUM.Launcher.cpp:16-36), which make the reference GPU library non re-entrant, and the
+// per-call OpenCL context + JIT (gpu:ExSUM.cpp:86-209).
+struct Ctx {
+    int device = -1;
+    int num_cu = 256;
+    int blocks_per_cu = 8;   // EXBLAS_BLOCKS_PER_CU
+    int ngroups = 32;        // EXBLAS_NGROUPS: global group accumulators the blocks add into
+    bool nontemporal = true; // EXBLAS_NT
+    long long *gacc = nullptr;   // [ngroups][NL] int64, zero between calls
+    unsigned *gflags = nullptr;  // non-finite input flags, zero between calls
+    // host-pointer API staging
+    hipStream_t stream = nullptr;
+    void *stage[3] = {nullptr, nullptr, nullptr};
+    size_t stage_bytes[3] = {0, 0, 0};
+    long long *d_record = nullptr;  // OUT_WORDS
+    long long *h_record = nullptr;  // pinned
+    // blas2/blas3 workspaces
+    void *ws = nullptr;
+    size_t ws_bytes = 0;
+    std::mutex mu;
+};
+
+Ctx &ctx(int device);
+void *stage_buf(Ctx &c, int slot, size_t bytes);
+void *workspace(Ctx &c, size_t bytes);
+[[noreturn]] void die(const char *what, hipError_t e, const char *file, int line);
+
+#define EXB_CHECK(expr)                                          \
+    do {                                                         \
+        hipError_t _e = (expr);                                  \
+        if (_e != hipSuccess) exb::die(#expr, _e, __FILE__, __LINE__); \
+    } while (0)
+
+// blas1.hip
+hipError_t exsum_dispatch(Ctx &c, const double *a, long long n, long long inca, int fpe, int early_exit,
+                          hipStream_t st, bool *supported);
+hipError_t exdot_dispatch(Ctx &c, const double *a, long long inca, const double *b, long long incb, long long n,
+                          int fpe, int early_exit, hipStream_t st, bool *supported);
+hipError_t finalize_groups(Ctx &c, hipStream_t st, long long *d_out);
+hipError_t finalize_sets(const long long *d_sets, int nsets, unsigned flags_or, hipStream_t st, long long *d_out);
+
+// blas2.hip / blas3.hip
+hipError_t exgemv_dispatch(Ctx &c, char transa, int m, int n, double alpha, const double *a, int lda,
+                           const double *x, int incx, double beta, double *y, int incy, int fpe, int early_exit,
+                           int round_mode, hipStream_t st);
+hipError_t exgemm_dispatch(Ctx &c, char transa, char transb, int m, int n, int k, double alpha, const double *a,
+                           int lda, const double *b, int ldb, double beta, double *cmat, int ldc, int fpe,
+                           int early_exit, int round_mode, hipStream_t st);
+
+int round_mode();
+
+}  // namespace exb

@@ -1,0 +1,269 @@
+// superacc.hip.h -- device-side Kulisch superaccumulator for gfx950 (CDNA4).
+//
+// Replaces, with a different geometry, the reference's OpenCL helpers Accumulate /
+// AccumulateWord / Normalize / Round (src/gpu/blas/blas1/ExSUM.Superacc.cl:27-209, twins of
+// src/cpu/blas/blas1/superaccumulator.hpp:132-194 and superaccumulator.cpp:80-162).
+//
+// Geometry (ours, chosen for the GPU): the exact sum is a fixed-point integer with LSB weight
+// 2^-1074 (the smallest subnormal), held as NL = 68 signed 64-bit limbs spaced 32 bits apart:
+//     value = 2^-1074 * sum_i limb[i] * 2^(32 i)
+// A double  +-M * 2^(p-1074)  (M < 2^53, p = max(biased_exp,1)-1 in [0,2045]) is split with pure
+// integer shifts into three 32-bit chunks of M << (p & 31) that are added to limbs p>>5 .. +2.
+// Each add moves a limb by < 2^32, so a limb survives 2^31 adds: with the API's `int n` no carry
+// handling is ever needed while streaming -- the reference's overflow-driven AccumulateWord loop
+// and its K = 12 carry-save bits (renormalise every 2^11 adds) disappear.  The range covers every
+// finite double incl. subnormals (the reference's 39-limb GPU geometry does not).
+// After the last add one carry-propagation pass produces normalised 32-bit digits; those are
+// re-cut into the reference's canonical 41 x 52-bit limbs (weight 2^(52(i-21)),
+// superaccumulator.cpp:14-22) for parity checks, and rounded once.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace exb {
+
+constexpr int NL = 68;          // limbs, 32-bit spacing
+constexpr int CANON = 41;       // reference canonical limbs (21 fraction + 20 exponent words)
+constexpr int CANON_DIGITS = 52;
+constexpr int CANON_FWORDS = 21;
+
+// layout of the int64 result record every finalize writes
+constexpr int OUT_EXACT = 0;    // bits of the correctly rounded double
+constexpr int OUT_REFMODE = 1;  // bits of the reference-compatible Round()
+constexpr int OUT_FLAGS = 2;    // bit0 +inf seen, bit1 -inf seen, bit2 NaN seen
+constexpr int OUT_CANON = 4;    // 41 canonical limbs
+constexpr int OUT_DIGITS = 48;  // 68 normalised digits ...
+constexpr int OUT_FLAGCNT = 116;  // ... followed by 3 flag indicators (+inf, -inf, NaN) and one pad word:
+constexpr int SET_WORDS = 72;   // words [48,120) form one "digit set", summable across ranks as int64
+constexpr int OUT_WORDS = 128;
+
+constexpr unsigned FLAG_PINF = 1u, FLAG_NINF = 2u, FLAG_NAN = 4u;
+
+// ---------------------------------------------------------------------------------------------
+// error-free transforms (ExSUM.FPE.cl:27-32 KnuthTwoSum; ExDOT.Superacc.cl:25-29 TwoProductFMA)
+// compiled with -ffp-contract=off: nothing here may be fused or reassociated
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double two_sum(double a, double b, double &s)
+{
+    double r = a + b;
+    double z = r - a;
+    s = (a - (r - z)) + (b - z);
+    return r;
+}
+
+__device__ __forceinline__ double two_prod(double a, double b, double &e)
+{
+    double p = a * b;
+    e = __builtin_fma(a, b, -p);
+    return p;
+}
+
+// As two_prod, but the error term is forced to 0 when the product is not finite (overflow or
+// non-finite input): fma(a,b,-inf) would be an opposite infinity and turn a legitimate +-inf
+// result into NaN further down.
+__device__ __forceinline__ double two_prod_safe(double a, double b, double &e)
+{
+    double p = a * b;
+    double t = __builtin_fma(a, b, -p);
+    e = __builtin_isfinite(p) ? t : 0.0;
+    return p;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LDS accumulation: one sub-accumulator column per (wave, lane % COPIES); limb-major layout
+// sacc[limb * COPIES + copy] so that the bank of an access depends on the copy only
+// ---------------------------------------------------------------------------------------------
+template <int COPIES>
+__device__ __forceinline__ void lds_add(long long *col, double x, unsigned &flags)
+{
+    const unsigned long long u = (unsigned long long)__double_as_longlong(x);
+    unsigned be = (unsigned)(u >> 52) & 0x7ffu;
+    unsigned long long m = u & 0x000fffffffffffffull;
+    if (be == 0x7ffu) {  // Inf / NaN never enter the integer accumulator
+        flags |= m ? FLAG_NAN : ((u >> 63) ? FLAG_NINF : FLAG_PINF);
+        return;
+    }
+    if (be) m |= 0x0010000000000000ull; else be = 1u;  // subnormals: no hidden bit, exponent 1
+    const unsigned p = be - 1u;
+    const unsigned idx = p >> 5, sh = p & 31u;
+    const unsigned long long lo = m << sh;                    // bits 0..63 of M << sh
+    const unsigned hi = (unsigned)((m >> 32) >> (32u - sh));  // bits 64..84 (0 when sh == 0)
+    long long c0 = (long long)(lo & 0xffffffffull);
+    long long c1 = (long long)(lo >> 32);
+    long long c2 = (long long)hi;
+    if (u >> 63) { c0 = -c0; c1 = -c1; c2 = -c2; }
+    unsigned long long *q = (unsigned long long *)(col + idx * COPIES);
+    // no-return LDS atomics (ds_add_u64); zero chunks still issue: cheaper than diverging
+    atomicAdd(q, (unsigned long long)c0);
+    atomicAdd(q + COPIES, (unsigned long long)c1);
+    atomicAdd(q + 2 * COPIES, (unsigned long long)c2);
+}
+
+// ---------------------------------------------------------------------------------------------
+// final step, run by ONE thread on NL limbs held in LDS/local memory
+// ---------------------------------------------------------------------------------------------
+// carry-propagate: digits 0..NL-2 end in [0,2^32), the top limb keeps the signed remainder
+__device__ inline void normalize_digits(long long *v)
+{
+    long long carry = 0;
+    for (int i = 0; i < NL - 1; ++i) {
+        long long t = v[i] + carry;
+        carry = t >> 32;  // arithmetic
+        v[i] = t & 0xffffffffll;
+    }
+    v[NL - 1] += carry;
+}
+
+// correctly rounded (RN-even) double of the normalised digits; returns the bit pattern
+__device__ inline unsigned long long round_exact_bits(const long long *v)
+{
+    const bool neg = v[NL - 1] < 0;
+    // magnitude digits
+    unsigned mag[NL];
+    if (!neg) {
+        for (int i = 0; i < NL; ++i) mag[i] = (unsigned)v[i];
+    } else {
+        unsigned long long c = 1;
+        for (int i = 0; i < NL; ++i) {
+            unsigned long long t = (unsigned long long)(~(unsigned)v[i]) + c;
+            mag[i] = (unsigned)t;
+            c = t >> 32;
+        }
+    }
+    int t = NL - 1;
+    while (t >= 0 && mag[t] == 0) --t;
+    const unsigned long long sign = neg ? 0x8000000000000000ull : 0ull;
+    if (t < 0) return 0ull;  // exact zero -> +0.0
+    const int lz = __builtin_clz(mag[t]);
+    const int msb = 32 * t + 31 - lz;
+    if (msb <= 52) {
+        // below 2^53 units of 2^-1074: exactly representable (subnormal or first binades)
+        unsigned long long val = ((unsigned long long)(t >= 1 ? mag[1] : 0u) << 32) | mag[0];
+        return sign | val;
+    }
+    const unsigned d1 = (t >= 1) ? mag[t - 1] : 0u, d2 = (t >= 2) ? mag[t - 2] : 0u;
+    unsigned long long w = ((unsigned long long)mag[t] << 32) | d1;  // leading one at bit 63-lz
+    unsigned rest;  // bits of d2 not consumed by the window
+    if (lz) {
+        w = (w << lz) | (unsigned long long)(d2 >> (32 - lz));
+        rest = d2 << lz;
+    } else {
+        rest = d2;
+    }
+    bool sticky = (w & 0x3ffull) != 0 || rest != 0;
+    for (int i = t - 3; i >= 0 && !sticky; --i) sticky = mag[i] != 0;
+    unsigned long long bits = ((unsigned long long)(msb - 52) << 52) + (w >> 11);
+    const bool rnd = (w >> 10) & 1ull;
+    if (rnd && (sticky || (bits & 1ull))) bits += 1;       // carries into the exponent naturally
+    if ((bits >> 52) >= 0x7ffull) bits = 0x7ff0000000000000ull;  // overflow -> inf
+    return sign | bits;
+}
+
+// two's-complement bit field [o, o+52) of the value held in the normalised digits
+__device__ inline long long digits_field52(const long long *v, int o)
+{
+    // 128-bit window starting at digit q = floor(o/32)
+    const int q = o >> 5, r = o & 31;  // arithmetic shift: o may be negative
+    auto dig = [&](int i) -> unsigned long long {
+        if (i < 0) return 0ull;
+        if (i >= NL - 1) {
+            // top limb is a signed 64-bit remainder: expand it into 32-bit sign-extended digits
+            const long long top = v[NL - 1];
+            const int k = i - (NL - 1);
+            if (k == 0) return (unsigned long long)(unsigned)top;
+            if (k == 1) return (unsigned long long)(unsigned)(top >> 32);
+            return (top < 0) ? 0xffffffffull : 0ull;
+        }
+        return (unsigned long long)(unsigned)v[i];
+    };
+    const unsigned long long lo = dig(q) | (dig(q + 1) << 32);
+    const unsigned long long hi = dig(q + 2) | (dig(q + 3) << 32);
+    const unsigned long long win = r ? ((lo >> r) | (hi << (64 - r))) : lo;
+    return (long long)(win & ((1ull << CANON_DIGITS) - 1));
+}
+
+// canonical 41 x 52-bit limbs of the reference (limb i weighs 2^(52(i-21)), so the LSB of limb 0
+// is 2^-1092 = our LSB shifted left by 18 bits); all limbs in [0,2^52) but the signed top one
+__device__ inline void digits_to_canon(const long long *v, long long *canon)
+{
+    for (int j = 0; j < CANON - 1; ++j) canon[j] = digits_field52(v, CANON_DIGITS * j - 18);
+    // top limb: everything from bit 52*40-18 up, sign-extended
+    const int o = CANON_DIGITS * (CANON - 1) - 18;
+    const int q = o >> 5, r = o & 31;
+    auto dig = [&](int i) -> unsigned long long {
+        if (i >= NL - 1) {
+            const long long top = v[NL - 1];
+            const int k = i - (NL - 1);
+            if (k == 0) return (unsigned long long)(unsigned)top;
+            if (k == 1) return (unsigned long long)(unsigned)(top >> 32);
+            return (top < 0) ? 0xffffffffull : 0ull;
+        }
+        return (unsigned long long)(unsigned)v[i];
+    };
+    const unsigned long long lo = dig(q) | (dig(q + 1) << 32);
+    const unsigned long long hi = dig(q + 2) | (dig(q + 3) << 32);
+    canon[CANON - 1] = (long long)(r ? ((lo >> r) | (hi << (64 - r))) : lo);
+}
+
+// Superaccumulator::Round restated for the device on canonical limbs, INCLUDING its defect
+// (superaccumulator.cpp:80-134; identical code in ExSUM.Superacc.cl:100-143): the
+// "reference" rounding mode.  Input limbs are already normalised.
+__device__ inline double round_reference(const long long *acc)
+{
+    const long long mask = (1ll << CANON_DIGITS) - 1;
+    const bool negative = acc[CANON - 1] < 0;
+    int i;
+    for (i = CANON - 1; i >= 0 && acc[i] == 0; --i) { }
+    if (negative) {
+        for (; i >= 0 && (acc[i] & mask) == mask; --i) { }
+    }
+    if (i < 0) return 0.0;
+    long long hiword = negative ? mask - acc[i] : acc[i];
+    double rounded = (double)hiword;
+    double hi = ldexp(rounded, (i - CANON_FWORDS) * CANON_DIGITS);
+    if (i == 0) return negative ? -hi : hi;
+    hiword -= __double2ll_rn(rounded);
+    double mid = ldexp((double)hiword, (i - CANON_FWORDS) * CANON_DIGITS);
+    long long sticky = 0;
+    for (int j = 0; j != i - 1; ++j) sticky |= negative ? (1ll << CANON_DIGITS) - acc[j] : acc[j];
+    long long loword = negative ? (1ll << CANON_DIGITS) - acc[i - 1] : acc[i - 1];
+    loword |= (sticky != 0);
+    double lo = ldexp((double)loword, (i - 1 - CANON_FWORDS) * CANON_DIGITS);
+    if (mid != 0) {
+        // OddRoundSumNonnegative (mylibm.hpp:156-171)
+        unsigned long long b = (unsigned long long)__double_as_longlong(mid + lo);
+        b |= (unsigned long long)(lo != 0.0);
+        lo = __longlong_as_double((long long)b);
+    }
+    hi = hi + lo;
+    return negative ? -hi : hi;
+}
+
+// One thread: v[NL] raw limbs -> record (normalised digits, canonical limbs, both roundings)
+__device__ inline void finish_record(long long *v, unsigned flags, long long *out)
+{
+    normalize_digits(v);
+    long long canon[CANON];
+    digits_to_canon(v, canon);
+    unsigned long long ex = round_exact_bits(v);
+    double rf = round_reference(canon);
+    if (flags) {
+        // IEEE semantics for non-finite inputs: NaN, or opposite infinities -> NaN; else +-inf
+        const bool nan = (flags & FLAG_NAN) || ((flags & FLAG_PINF) && (flags & FLAG_NINF));
+        ex = nan ? 0x7ff8000000000000ull
+                 : ((flags & FLAG_NINF) ? 0xfff0000000000000ull : 0x7ff0000000000000ull);
+        rf = __longlong_as_double((long long)ex);
+    }
+    out[OUT_EXACT] = (long long)ex;
+    out[OUT_REFMODE] = __double_as_longlong(rf);
+    out[OUT_FLAGS] = (long long)flags;
+    out[3] = 0;
+    for (int j = 0; j < CANON; ++j) out[OUT_CANON + j] = canon[j];
+    for (int j = 0; j < NL; ++j) out[OUT_DIGITS + j] = v[j];
+    out[OUT_FLAGCNT + 0] = (flags & FLAG_PINF) ? 1 : 0;
+    out[OUT_FLAGCNT + 1] = (flags & FLAG_NINF) ? 1 : 0;
+    out[OUT_FLAGCNT + 2] = (flags & FLAG_NAN) ? 1 : 0;
+    out[OUT_FLAGCNT + 3] = 0;
+}
+
+}  // namespace exb

@@ -1,0 +1,124 @@
+/*
+ * exblas_hip.h -- C ABI of libexblas.so, the MI355X (gfx950) replacement for the reference's
+ * OpenCL backend (src/gpu of nikolovjovan/exblas).  Plain pointers and sizes only.
+ *
+ * Two layers:
+ *  (1) host-pointer entry points with exactly the argument meaning of the reference's public C++
+ *      API (include/blas1.hpp:48,74; blas2.hpp:95; blas3.hpp:56) -- what its tests and examples call;
+ *      the C++ overloads themselves (exsum/exdot/exgemv/exgemm, global namespace) are declared in
+ *      include/blas1.hpp, blas2.hpp, blas3.hpp of this repository and exported by the same library.
+ *  (2) device-pointer, stream-ordered entry points underneath: what the reference's launcher layer
+ *      (extern "C" initEx* / Ex* / closeEx* on cl_mem, src/gpu/blas/blas1/ExSUM.Launcher.hpp,
+ *      ExDOT.Launcher.hpp, blas2/ExGEMV.Launcher.hpp, blas3/ExGEMM.Launcher.hpp) is to OpenCL.
+ *      These keep data resident in HBM and are what bench.py and the multi-GPU path drive.
+ *
+ * Error behaviour mirrors the reference: no error channel in the BLAS-style calls;
+ * fpe < 0 or a HIP failure prints to stderr and exit(EXIT_FAILURE)s (cpu:ExSUM.cpp:25-28,
+ * gpu:ExSUM.cpp:111-115); Ng <= 0 returns 0.0 (ExDOT.cpp:70-71).  The *_dev functions return a
+ * hipError_t-compatible int instead of exiting (0 = success).
+ *
+ * Rounding: EXBLAS_ROUND=exact (default; correctly rounded = the MPFR oracle of
+ * tests/test.exsum.gpu.cpp:23-38) or EXBLAS_ROUND=reference (bug-compatible with
+ * Superaccumulator::Round, superaccumulator.cpp:80-134).  The limbs are identical in both.
+ */
+#ifndef EXBLAS_HIP_H_
+#define EXBLAS_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* result record written by every *_dev reduction: EXBLAS_OUT_WORDS int64 words */
+#define EXBLAS_OUT_WORDS 128
+#define EXBLAS_OUT_EXACT 0    /* bit pattern of the correctly rounded double */
+#define EXBLAS_OUT_REFMODE 1  /* bit pattern of the reference-compatible rounding */
+#define EXBLAS_OUT_FLAGS 2    /* bit0 +inf, bit1 -inf, bit2 NaN seen in the input */
+#define EXBLAS_OUT_CANON 4    /* 41 canonical limbs (52-bit, reference geometry) */
+#define EXBLAS_OUT_DIGITS 48  /* 68 normalised 32-bit digits, then 3 flag indicators + 1 pad word: */
+#define EXBLAS_SET_WORDS 72   /* words [48,120) = one "digit set", the int64-sum all-reduce payload */
+#define EXBLAS_NDIGITS 68
+#define EXBLAS_NCANON 41
+
+/* generator kinds for exblas_gen_dev (restating the distributions of src/common/common.cpp) */
+#define EXBLAS_GEN_NAIVE 0
+#define EXBLAS_GEN_FPUNIFORM 1
+#define EXBLAS_GEN_LOGNORMAL 2
+#define EXBLAS_GEN_ILLCOND 3
+#define EXBLAS_GEN_CANCEL 4
+#define EXBLAS_GEN_FPUNIFORM_SIGNED 5
+
+/* ---- context ------------------------------------------------------------------------------ */
+/* Lazily creates the per-device context (workspace, CU count).  device < 0: current device.
+ * Replaces the per-call OpenCL platform/context/queue/JIT of gpu:ExSUM.cpp:86-209. */
+int exblas_hip_init(int device);
+int exblas_hip_device_count(void);
+const char *exblas_hip_version(void);
+/* 0 = exact, 1 = reference; overrides EXBLAS_ROUND for the host-pointer API */
+void exblas_set_round_mode(int mode);
+int exblas_get_round_mode(void);
+
+/* ---- (2) device-pointer layer -------------------------------------------------------------- */
+/* ExSUM over d_a[i*inca], i < n (offset already applied to the pointer).  Replaces
+ * initExSUM/ExSUM/closeExSUM (ExSUM.Launcher.hpp) = kernels ExSUM + ExSUMComplete
+ * (ExSUM.Superacc.cl:211-356, ExSUM.FPE.cl:230-388).  fpe/early_exit select the variant exactly
+ * as gpu:ExSUM.cpp:64-84.  d_out: EXBLAS_OUT_WORDS int64 in device memory. */
+int exblas_exsum_dev(const double *d_a, int64_t n, int64_t inca, int fpe, int early_exit,
+                     void *stream, int64_t *d_out);
+/* ExDOT.  Replaces initExDOT/ExDOT/closeExDOT (ExDOT.Launcher.hpp) = kernels ExDOT +
+ * ExDOTComplete (ExDOT.Superacc.cl:217-359, ExDOT.FPE.cl:201-345); variants as ExDOT.cpp:69-98. */
+int exblas_exdot_dev(const double *d_a, int64_t inca, const double *d_b, int64_t incb, int64_t n,
+                     int fpe, int early_exit, void *stream, int64_t *d_out);
+/* The two phases of the calls above, separately: *_accumulate_dev launches only the streaming kernel
+ * and adds its result into the context's (zero-initialised) accumulators, so several arrays can be
+ * folded into ONE exact sum; exblas_finish_dev carry-propagates, rounds, writes the record and
+ * leaves the accumulators zero again.  bench.py brackets the streaming kernel with events this way. */
+int exblas_exsum_accumulate_dev(const double *d_a, int64_t n, int64_t inca, int fpe, int early_exit,
+                                void *stream);
+int exblas_exdot_accumulate_dev(const double *d_a, int64_t inca, const double *d_b, int64_t incb,
+                                int64_t n, int fpe, int early_exit, void *stream);
+int exblas_finish_dev(void *stream, int64_t *d_out);
+/* Sum `nsets` digit sets (EXBLAS_SET_WORDS int64 each = words [48,120) of a record, e.g. the
+ * all-reduced payloads of several GPUs), carry-propagate once and round: the "single global
+ * carry-propagated normalise".  d_out may alias d_digit_sets - EXBLAS_OUT_DIGITS (in-place).
+ * Plays the role of MPI_Reduce + Round in cpu:ExSUM.cpp:142-156. flags_or: OR of the ranks' flags. */
+int exblas_finalize_dev(const int64_t *d_digit_sets, int nsets, uint32_t flags_or, void *stream,
+                        int64_t *d_out);
+/* ExGEMV on device pointers, column-major A (ExGEMV.Launcher.hpp; kernels gemv/gemvT,
+ * ExGEMV.Superacc.cl:192-392).  y is updated in place. */
+int exblas_exgemv_dev(char transa, int m, int n, double alpha, const double *d_a, int lda,
+                      const double *d_x, int incx, double beta, double *d_y, int incy, int fpe,
+                      int early_exit, void *stream);
+/* ExGEMM on device pointers, row-major (ExGEMM.Launcher.hpp; kernel gemm, ExGEMM.Superacc.cl:200-283). */
+int exblas_exgemm_dev(char transa, char transb, int m, int n, int k, double alpha,
+                      const double *d_a, int lda, const double *d_b, int ldb, double beta,
+                      double *d_c, int ldc, int fpe, int early_exit, void *stream);
+/* Deterministic counter-based input generators, bit-identical to oracle/exblas_oracle.c:orc_gen_ctr;
+ * element index range [first, first+count) of a vector of n_total elements. */
+int exblas_gen_dev(int kind, uint64_t seed, int64_t first, int64_t count, int64_t n_total,
+                   double p0, double p1, double *d_out, void *stream);
+/* Plain streaming read (sum of doubles, not exact): measures the box's achievable read bandwidth,
+ * the second roofline denominator of BASELINE.md section 3. */
+int exblas_stream_read_dev(const double *d_a, int64_t n, void *stream, double *d_sink);
+
+/* ---- (1) host-pointer layer (reference semantics; copies H2D per call like gpu:ExSUM.cpp:126) -- */
+double exblas_exsum(int Ng, const double *ag, int inca, int offset, int fpe, int early_exit);
+double exblas_exdot(int Ng, const double *ag, int inca, int offseta, const double *bg, int incb,
+                    int offsetb, int fpe, int early_exit);
+int exblas_exgemv(char transa, int m, int n, double alpha, const double *a, int lda, int offseta,
+                  const double *x, int incx, int offsetx, double beta, double *y, int incy,
+                  int offsety, int fpe, int early_exit);
+int exblas_exgemm(char transa, char transb, int m, int n, int k, double alpha, const double *a,
+                  int lda, const double *b, int ldb, double beta, double *c, int ldc, int fpe,
+                  int early_exit);
+/* as exblas_exsum / exblas_exdot, additionally returning the full record (limbs, both roundings) */
+int exblas_exsum_record(int Ng, const double *ag, int inca, int offset, int fpe, int early_exit,
+                        int64_t *out_words);
+int exblas_exdot_record(int Ng, const double *ag, int inca, int offseta, const double *bg, int incb,
+                        int offsetb, int fpe, int early_exit, int64_t *out_words);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EXBLAS_HIP_H_ */

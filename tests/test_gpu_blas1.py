@@ -1,0 +1,154 @@
+"""GPU parity tests for ExSUM / ExDOT: the HIP path (through the C ABI) against the oracle.
+
+Bit-exact bar: canonical limbs equal, both roundings equal, for every (fpe, early_exit) variant."""
+import numpy as np
+import pytest
+
+from helpers import (FPE_VARIANTS_DOT, FPE_VARIANTS_SUM, exact_int_from_canon, exact_int_from_digits, golden_cases,
+                     load_golden, same_double)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ex():
+    import torch
+    import exblas_amd
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    exblas_amd.load_library().exblas_hip_init(-1)
+    return exblas_amd
+
+
+def _check_record(rec, limbs, exact, refmode, what):
+    assert (rec.canon == limbs).all(), (what, "canonical limbs differ")
+    assert same_double(rec.exact, exact), (what, rec.exact, exact)
+    assert same_double(rec.refmode, refmode), (what, rec.refmode, refmode)
+    # the all-reduce payload holds the same integer (canonical LSB is 2^-1092 = 2^-1074 >> 18)
+    assert exact_int_from_digits(rec.digits) << 18 == exact_int_from_canon(rec.canon), what
+
+
+def test_exsum_golden_all_variants(ex):
+    g = load_golden("exsum_golden.npz")
+    for name, i, a in golden_cases(g, "data"):
+        for fpe, ee in FPE_VARIANTS_SUM:
+            rec = ex.exsum_record(a.size, a if a.size else np.zeros(1), 1, 0, fpe, ee)
+            _check_record(rec, g["limbs"][i], g["mpfr"][i], g["refmode"][i], (name, fpe, ee))
+
+
+def test_exdot_golden_all_variants(ex):
+    g = load_golden("exdot_golden.npz")
+    for name, i, a, b in golden_cases(g, "a", "b"):
+        for fpe, ee in FPE_VARIANTS_DOT:
+            rec = ex.exdot_record(a.size, a, 1, 0, b, 1, 0, fpe, ee)
+            assert (rec.canon == g["limbs"][i]).all(), (name, fpe, ee)
+            assert same_double(rec.exact, g["mpfr"][i]), (name, fpe, ee)
+
+
+@pytest.mark.parametrize("kind,p0,p1", [("naive", 0, 0), ("fpuniform", 10, 0), ("lognormal", 0.0, 2.0),
+                                         ("lognormal", 0.0, 50.0), ("ill_cond", 1e32, 0.0), ("cancel", 50.0, 0.0),
+                                         ("fpuniform_signed", 1000.0, 500.0)])
+def test_exsum_vs_oracle_mid_sizes(ex, oracle, kind, p0, p1):
+    import torch
+    for n in (100003, 1 << 20, (1 << 21) + 5):
+        x = ex.gen_dev(kind, n, 7, p0, p1)
+        host = oracle.gen(kind, n, 7, p0, p1)
+        assert (x.cpu().numpy().view(np.int64) == host.view(np.int64)).all(), "GPU generator differs from oracle's"
+        r0, l0 = oracle.exsum_omp(host, 8, True, 8, limbs=True)
+        rref = oracle.round_limbs(l0, oracle.ROUND_REFERENCE)
+        for fpe, ee in FPE_VARIANTS_SUM:
+            rec = ex.read_record(ex.exsum_dev(x, fpe, ee))
+            _check_record(rec, l0, r0, rref, (kind, n, fpe, ee))
+        torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("kind,p0,p1", [("naive", 0, 0), ("lognormal", 0.0, 2.0), ("ill_cond", 1e32, 0.0),
+                                         ("fpuniform_signed", 400.0, 200.0)])
+def test_exdot_vs_oracle_mid_sizes(ex, oracle, kind, p0, p1):
+    for n in (100003, 1 << 20):
+        x, y = ex.gen_dev(kind, n, 8, p0, p1), ex.gen_dev(kind, n, 9, p0, p1)
+        ha, hb = oracle.gen(kind, n, 8, p0, p1), oracle.gen(kind, n, 9, p0, p1)
+        r0, l0 = oracle.exdot_omp(ha, hb, 8, True, 8, limbs=True)
+        for fpe, ee in FPE_VARIANTS_DOT:
+            rec = ex.read_record(ex.exdot_dev(x, y, fpe, ee))
+            assert (rec.canon == l0).all(), (kind, n, fpe, ee)
+            assert same_double(rec.exact, r0), (kind, n, fpe, ee)
+
+
+def test_strided_offset_misaligned(ex, oracle):
+    a = oracle.gen("ill_cond", 50001, 5, 1e32)
+    b = oracle.gen("lognormal", 50001, 6, 0.0, 2.0)
+    for inca, off in ((1, 0), (1, 1), (1, 3), (2, 0), (3, 1), (7, 5)):
+        n = (a.size - off + inca - 1) // inca
+        r0, l0 = oracle.exsum(a, 0, inca=inca, offset=off, n=n, limbs=True)
+        d0, m0 = oracle.exdot(a, b, 0, inca=inca, offa=off, incb=inca, offb=off, n=n, limbs=True)
+        for fpe, ee in ((0, False), (4, False), (8, True)):
+            rec = ex.exsum_record(n, a, inca, off, fpe, ee)
+            assert (rec.canon == l0).all() and same_double(rec.exact, r0), (inca, off, fpe, ee)
+            rec = ex.exdot_record(n, a, inca, off, b, inca, off, fpe, ee)
+            assert (rec.canon == m0).all() and same_double(rec.exact, d0), (inca, off, fpe, ee)
+
+
+def test_reference_api_semantics(ex, oracle):
+    a = oracle.gen("lognormal", 4097, 2, 0.0, 2.0)
+    want = oracle.exsum(a, 0)
+    assert ex.exsum(a.size, a, 1, 0, 0) == want
+    assert ex.exsum(a.size, a, 1, 0, 8, True, True) == want
+    assert ex.exsum(a.size, a, 1, 0, 9) == 0.0            # unsupported variant -> 0.0 (gpu:ExSUM.cpp:83)
+    assert ex.exsum(0, a, 1, 0, 4) == 0.0
+    assert ex.exdot(0, a, 1, 0, a, 1, 0, 4) == 0.0        # ExDOT.cpp:70-71
+    assert ex.exdot(a.size, a, 1, 0, a, 1, 0, 5) == oracle.exdot(a, a, 0)
+    lib = ex.load_library()
+    lib.exblas_set_round_mode(1)
+    try:
+        neg = np.array([-1.5])
+        assert ex.exsum(1, neg, 1, 0, 0) == oracle.exsum(neg, 0, mode=oracle.ROUND_REFERENCE) != -1.5
+    finally:
+        lib.exblas_set_round_mode(0)
+    assert ex.exsum(1, np.array([-1.5]), 1, 0, 0) == -1.5
+
+
+def test_nonfinite_policy(ex):
+    inf, nan = np.inf, np.nan
+    base = np.ones(5000)
+    for fpe, ee in ((0, False), (4, False), (8, True)):
+        for vals, want in (([inf], inf), ([-inf], -inf), ([inf, -inf], nan), ([nan], nan), ([inf, inf], inf)):
+            a = base.copy()
+            a[100:100 + len(vals)] = vals
+            got = ex.exsum(a.size, a, 1, 0, fpe, ee)
+            assert (np.isnan(want) and np.isnan(got)) or got == want, (fpe, ee, vals, got)
+        a = np.full(4096, np.finfo(np.float64).max)
+        b = np.full(4096, 2.0)
+        assert ex.exdot(a.size, a, 1, 0, b, 1, 0, fpe if fpe else 0, ee) == inf
+
+
+def test_full_size_properties(ex, oracle):
+    """n = 2^28 (BASELINE config): size-independent properties + one full oracle comparison."""
+    import torch
+    n = 1 << 28
+    x = ex.gen_dev("cancel", n, 1, 50.0)
+    rec = ex.read_record(ex.exsum_dev(x, 8, True))
+    assert rec.exact == 1.0                       # exact sum is 1 + 2^-60 by construction
+    assert exact_int_from_digits(rec.digits) == (1 << 1074) + (1 << 1014)
+    del x
+    x = ex.gen_dev("ill_cond", n, 1, 1e32)
+    recs = [ex.read_record(ex.exsum_dev(x, fpe, ee)) for fpe, ee in ((8, True), (4, True), (0, False), (3, False))]
+    for r in recs[1:]:
+        assert (r.canon == recs[0].canon).all() and same_double(r.exact, recs[0].exact)
+    # linearity: sum(x) == sum(x[:k]) + sum(x[k:]) as exact integers, for an odd split
+    k = 123456789
+    p1 = ex.read_record(ex.exsum_dev(x[:k], 8, True))
+    p2 = ex.read_record(ex.exsum_dev(x[k:], 6, True))
+    assert exact_int_from_digits(p1.digits) + exact_int_from_digits(p2.digits) == exact_int_from_digits(recs[0].digits)
+    # the whole vector against the CPU oracle (OpenMP, FPE8-EE)
+    host = x.cpu().numpy()
+    r0, l0 = oracle.exsum_omp(host, 8, True, 16, limbs=True)
+    assert (recs[0].canon == l0).all() and same_double(recs[0].exact, r0)
+    # dot of the vector with a second one, against the oracle
+    y = ex.gen_dev("ill_cond", n, 2, 1e32)
+    d = ex.read_record(ex.exdot_dev(x, y, 8, True))
+    d2 = ex.read_record(ex.exdot_dev(x, y, 0, False))
+    assert (d.canon == d2.canon).all()
+    hy = y.cpu().numpy()
+    r1, l1 = oracle.exdot_omp(host, hy, 8, True, 16, limbs=True)
+    assert (d.canon == l1).all() and same_double(d.exact, r1)
+    torch.cuda.synchronize()

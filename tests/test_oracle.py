@@ -1,0 +1,151 @@
+"""CPU suite: pins the oracle (oracle/exblas_oracle.c) against the golden vectors, the compiled
+reference core (oracle/_ref, when present), MPFR and Python's exact fsum/Fraction arithmetic."""
+import math
+
+import numpy as np
+import pytest
+
+from helpers import (FPE_VARIANTS_DOT, FPE_VARIANTS_SUM, exact_int_from_canon, exact_sum_int, golden_cases,
+                     load_golden, same_double)
+
+TINY = np.finfo(np.float64).tiny
+
+
+def test_exsum_golden_limbs_and_roundings(oracle):
+    g = load_golden("exsum_golden.npz")
+    n = 0
+    for name, i, a in golden_cases(g, "data"):
+        r, limbs = oracle.exsum(a, 0, limbs=True)
+        assert (limbs == g["limbs"][i]).all(), name
+        assert same_double(r, g["exact"][i]), name
+        assert same_double(r, g["mpfr"][i]), name  # exact mode == MPFR on every fixture
+        assert same_double(oracle.exsum(a, 0, mode=oracle.ROUND_REFERENCE), g["refmode"][i]), name
+        n += 1
+    assert n > 150
+
+
+def test_exsum_all_variants_same_limbs(oracle):
+    g = load_golden("exsum_golden.npz")
+    for name, i, a in golden_cases(g, "data"):
+        if a.size > 1000:
+            continue
+        for fpe, ee in FPE_VARIANTS_SUM:
+            r, limbs = oracle.exsum(a, fpe, ee, limbs=True)
+            assert (limbs == g["limbs"][i]).all(), (name, fpe, ee)
+            assert same_double(r, g["exact"][i]), (name, fpe, ee)
+
+
+def test_exsum_golden_against_bigint(oracle):
+    g = load_golden("exsum_golden.npz")
+    for name, i, a in golden_cases(g, "data"):
+        if a.size > 1000:
+            continue
+        assert exact_int_from_canon(g["limbs"][i]) == exact_sum_int(a) << 18, name
+
+
+def test_exsum_vs_fsum_random(oracle):
+    rng = np.random.default_rng(7)
+    for _ in range(50):
+        n = int(rng.integers(1, 3000))
+        a = rng.standard_normal(n) * np.exp2(rng.integers(-300, 300, n).astype(np.float64))
+        assert oracle.exsum(a, 8, True) == math.fsum(a)
+        assert oracle.exsum(a, 0) == math.fsum(a)
+
+
+def test_unsupported_variants_return_zero(oracle):
+    a = np.ones(16)
+    assert oracle.exsum(a, 9, False) == 0.0      # cpu:ExSUM.cpp:99
+    assert oracle.exsum(a, 9, True) == 0.0
+    assert oracle.exdot(a, a, 9, False) == 0.0
+    assert oracle.exdot(np.zeros(0), np.zeros(0), 0) == 0.0  # ExDOT.cpp:70-71
+
+
+def test_strided_and_offset(oracle):
+    a = oracle.gen("ill_cond", 4000, 5, 1e32)
+    for inca, off in ((1, 0), (2, 0), (3, 1), (7, 5)):
+        n = (a.size - off + inca - 1) // inca
+        ref = math.fsum(a[off::inca][:n])
+        for fpe, ee in FPE_VARIANTS_SUM:
+            assert oracle.exsum(a, fpe, ee, inca=inca, offset=off, n=n) == ref
+
+
+def test_compiled_reference_agrees(oracle):
+    """oracle == the reference's own compiled arithmetic core, limb for limb, for every variant."""
+    if oracle.ref() is None:
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    ndiff = 0
+    for seed in range(1, 41):
+        a = oracle.ref_gen("ill_cond", 1 << 12, seed, 1e32)
+        r0, l0 = oracle.exsum(a, 0, limbs=True)
+        for fpe, ee in FPE_VARIANTS_SUM:
+            for nt in (1, 3):
+                rr, lr = oracle.ref_exsum(a, fpe, ee, nthreads=nt, limbs=True)
+                assert (lr == l0).all(), (seed, fpe, ee, nt)
+                assert same_double(rr, oracle.exsum(a, 0, mode=oracle.ROUND_REFERENCE)), (seed, fpe, ee)
+        ndiff += oracle.ref_exsum(a, 0) != r0
+    # the reference's Round() is off by one ulp on a sizeable fraction of these inputs
+    assert 0 < ndiff < 40
+
+
+def test_mpfr_agrees(oracle):
+    if oracle.mpfr() is None:
+        pytest.skip("libmpfr_oracle.so not built")
+    for kind, p0, p1 in (("lognormal", 0, 50), ("ill_cond", 1e32, 0), ("cancel", 60, 0), ("fpuniform", 600, 300)):
+        a, b = oracle.gen(kind, 5003, 21, p0, p1), oracle.gen(kind, 5003, 22, p0, p1)
+        assert same_double(oracle.exsum(a, 8, True), oracle.mpfr_exsum(a))
+        assert same_double(oracle.exdot(a, b, 8, True), oracle.mpfr_exdot(a, b))
+
+
+def test_exdot_golden(oracle):
+    g = load_golden("exdot_golden.npz")
+    for name, i, a, b in golden_cases(g, "a", "b"):
+        for fpe, ee in FPE_VARIANTS_DOT:
+            r, limbs = oracle.exdot(a, b, fpe, ee, limbs=True)
+            assert (limbs == g["limbs"][i]).all(), (name, fpe, ee)
+            assert same_double(r, g["mpfr"][i]), (name, fpe, ee)
+
+
+def test_omp_slicing_is_exact(oracle):
+    a = oracle.gen("ill_cond", 1 << 18, 3, 1e32)
+    b = oracle.gen("ill_cond", 1 << 18, 4, 1e32)
+    r0, l0 = oracle.exsum(a, 0, limbs=True)
+    d0, m0 = oracle.exdot(a, b, 0, limbs=True)
+    for nt in (1, 2, 5, 8):
+        r, l = oracle.exsum_omp(a, 8, True, nt, limbs=True)
+        assert (l == l0).all() and r == r0
+        d, m = oracle.exdot_omp(a, b, 8, True, nt, limbs=True)
+        assert (m == m0).all() and d == d0
+
+
+def test_generators_shape(oracle):
+    a = oracle.gen("cancel", 10000, 1, 50)
+    assert oracle.exsum(a, 8, True) == 1.0   # exact sum is 1 + 2^-60
+    assert float(np.sum(np.abs(a))) > 1e15
+    a = oracle.gen("ill_cond", 10000, 1, 1e32)
+    assert np.abs(a).max() < 2.0**55 and np.abs(a[:5000]).max() > 2.0**40
+    # slices of the counter-based stream are position-independent
+    full = oracle.gen("lognormal", 1000, 9, 0.0, 50.0)
+    part = oracle.gen("lognormal", 1000, 9, 0.0, 50.0, first=300, count=200)
+    assert (full[300:500] == part).all()
+
+
+def test_gemv_gemm_oracle_vs_mpfr(oracle):
+    if oracle.mpfr() is None:
+        pytest.skip("libmpfr_oracle.so not built")
+    m, n = 37, 53
+    a = oracle.gen("fpuniform_signed", m * n, 31, 40, 20)
+    x = oracle.gen("fpuniform_signed", max(m, n), 32, 40, 20)
+    y = oracle.gen("fpuniform_signed", max(m, n), 33, 40, 20)
+    for trans in ("N", "T"):
+        rows, inner = (n, m) if trans == "T" else (m, n)
+        ref = oracle.mpfr_exgemv(trans, m, n, 1.0, a, m, x[:inner], 1.0, y[:rows])
+        for fpe, ee in ((0, False), (3, False), (8, False), (4, True), (8, True)):
+            got = oracle.exgemv(trans, m, n, 1.0, a, m, x[:inner], 1.0, y[:rows], fpe, ee)
+            assert (got == ref).all(), (trans, fpe, ee)
+    k = 29
+    A = oracle.gen("fpuniform_signed", m * k, 41, 30, 10)
+    B = oracle.gen("fpuniform_signed", k * n, 42, 30, 10)
+    dots = oracle.mpfr_exgemm_dots(m, n, k, A, k, B, n)
+    for fpe, ee in ((0, False), (3, False), (8, True)):
+        got = oracle.exgemm("N", "N", m, n, k, 1.0, A, k, B, n, 0.0, np.zeros(m * n), n, fpe, ee)
+        assert (got.reshape(m, n) == dots).all(), (fpe, ee)
