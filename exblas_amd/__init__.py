@@ -48,6 +48,14 @@ def load_library():
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"exblas_amd: {LIB_PATH} is missing and hipcc is not available; "
                           "there is no CPU fallback")
+    # PyTorch wheels bundle their own libamdhip64/libhsa-runtime64.  Two HIP runtimes in one process do
+    # not share devices, streams or pointers (and the second one to initialise finds no device), so when
+    # torch is importable it must be loaded FIRST: libexblas.so's NEEDED libamdhip64.so.7 then resolves to
+    # the runtime torch already mapped.  Stand-alone C/C++ users simply get /opt/rocm's runtime.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, i64, i32, dbl = C.c_void_p, C.c_int64, C.c_int, C.c_double
     L.exblas_hip_init.argtypes = [i32]

@@ -29,6 +29,10 @@ __device__ __forceinline__ d2_t ld2(const d2_t *p)
 constexpr int BLOCK = 256;
 constexpr int WAVES = BLOCK / 64;
 
+// biased exponent field of a double, and the guard threshold 2^1000 (see fpe_absorb)
+__device__ __forceinline__ unsigned expo_field(double x) { return ((unsigned)__double2hiint(x) >> 20) & 0x7ffu; }
+constexpr unsigned BIG_EXPO = 1023u + 1000u;
+
 // ---------------------------------------------------------------------------------------------
 // per-lane floating-point expansion
 // ---------------------------------------------------------------------------------------------
@@ -40,6 +44,28 @@ __device__ __forceinline__ void fpe_absorb(double (&a)[N > 0 ? N : 1], double (&
 #pragma unroll
         for (int j = 0; j < CNT; ++j) lds_add<COPIES>(col, x[j], flags);
     } else {
+        if (from == 0) {
+            // Range guard (one wave-uniform test per tile): TwoSum is only error-free while a + x stays
+            // finite.  Elements of magnitude >= 2^1000 and Inf/NaN bypass the expansion and go straight to
+            // the integer accumulator (which holds them exactly, resp. classifies them), and a[0] is spilled
+            // once it reaches 2^1000 -- so a[0] never exceeds (1 + CNT) * 2^1000 and cannot overflow.  The
+            // reference has no such guard (ExSUM.FPE.hpp:408 "TODO ... Inf/Overflow/NaN").
+            unsigned mx = expo_field(a[0]);
+#pragma unroll
+            for (int j = 0; j < CNT; ++j) mx = max(mx, expo_field(x[j]));
+            if (__any(mx >= BIG_EXPO)) {
+#pragma unroll
+                for (int j = 0; j < CNT; ++j)
+                    if (expo_field(x[j]) >= BIG_EXPO) {
+                        lds_add<COPIES>(col, x[j], flags);
+                        x[j] = 0.0;
+                    }
+                if (expo_field(a[0]) >= BIG_EXPO) {
+                    lds_add<COPIES>(col, a[0], flags);
+                    a[0] = 0.0;
+                }
+            }
+        }
         bool live = true;
 #pragma unroll
         for (int i = 0; i < N; ++i) {
@@ -59,13 +85,9 @@ __device__ __forceinline__ void fpe_absorb(double (&a)[N > 0 ? N : 1], double (&
             }
         }
         if (live) {
-            // residues of a non-finite element are NaN by-products: the lane's a[0] carries the
-            // IEEE class of its inputs (inf + finite = inf, inf - inf = NaN) and is classified at
-            // the final flush, so flags raised here are dropped
-            unsigned by_product = 0;
 #pragma unroll
             for (int j = 0; j < CNT; ++j)
-                if (x[j] != 0.0) lds_add<COPIES>(col, x[j], by_product);
+                if (x[j] != 0.0) lds_add<COPIES>(col, x[j], flags);
         }
     }
 }
@@ -76,8 +98,7 @@ __device__ __forceinline__ void fpe_flush(double (&a)[N > 0 ? N : 1], long long 
     if constexpr (N > 0) {
 #pragma unroll
         for (int i = 0; i < N; ++i) {
-            unsigned by_product = 0;
-            if (a[i] != 0.0) lds_add<COPIES>(col, a[i], i == 0 ? flags : by_product);
+            if (a[i] != 0.0) lds_add<COPIES>(col, a[i], flags);
             a[i] = 0.0;
         }
     }
