@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Condense gpurun_out/{prof,pmc_fetch,pmc_write} (rocprofv3 CSV) into tracked files under profiles/.
+
+usage: tools/summarize_prof.py <round-tag>      e.g. r01
+Writes profiles/<tag>_kernel_stats.csv (the rocprofv3 --kernel-trace --stats summary, verbatim),
+profiles/<tag>_pmc_hbm.csv (per-kernel mean FETCH_SIZE / WRITE_SIZE) and profiles/hbm_traffic.json
+(per-launch HBM bytes, corrected as MI355X_MICROARCH.md section HBM prescribes: FETCH_SIZE counts 64 B per
+128-B request on gfx950 for wide coalesced streaming reads -> x2; the factor is re-calibrated here on
+k_stream_read, which reads exactly 8*n bytes).
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+out = os.path.join(ROOT, "profiles")
+os.makedirs(out, exist_ok=True)
+
+
+def one(pattern):
+    g = glob.glob(os.path.join(ROOT, "gpurun_out", pattern))
+    return g[0] if g else None
+
+
+ks = one("prof/*/*_kernel_stats.csv")
+if ks:
+    shutil.copy(ks, os.path.join(out, f"{tag}_kernel_stats.csv"))
+
+
+def short(name):
+    for k in ("k_exsum", "k_exdot", "k_stream_read", "k_finalize", "k_gen", "k_gemv", "k_gemm"):
+        if k in name:
+            return k
+    return None
+
+
+means = collections.defaultdict(dict)
+for which, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+    f = one(f"{which}/*/*_counter_collection.csv")
+    if not f:
+        continue
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        k = short(r["Kernel_Name"])
+        if k and r["Counter_Name"] == counter:
+            acc[k].append(float(r["Counter_Value"]))
+    for k, v in acc.items():
+        means[k][counter] = sum(v) / len(v)
+
+if means:
+    with open(os.path.join(out, f"{tag}_pmc_hbm.csv"), "w") as fh:
+        fh.write("kernel,FETCH_SIZE_KB_mean,WRITE_SIZE_KB_mean\n")
+        for k, d in sorted(means.items()):
+            fh.write(f"{k},{d.get('FETCH_SIZE', '')},{d.get('WRITE_SIZE', '')}\n")
+    n = 1 << 28
+    calib = 2.0
+    if "k_stream_read" in means and means["k_stream_read"].get("FETCH_SIZE"):
+        calib = (8.0 * n) / (means["k_stream_read"]["FETCH_SIZE"] * 1024.0)
+    traffic = {"_note": f"HBM bytes per launch = FETCH_SIZE[KB]*1024*{calib:.4f} + WRITE_SIZE[KB]*1024; "
+                        f"read factor calibrated on k_stream_read (exactly {8 * n} bytes), round {tag}"}
+    for k, d in means.items():
+        traffic[k] = d.get("FETCH_SIZE", 0.0) * 1024.0 * calib + d.get("WRITE_SIZE", 0.0) * 1024.0
+    json.dump(traffic, open(os.path.join(out, "hbm_traffic.json"), "w"), indent=1)
+    print(json.dumps(traffic, indent=1))
