@@ -129,7 +129,7 @@ __device__ __forceinline__ void block_epilogue(long long *s_acc, unsigned flags,
 // ---------------------------------------------------------------------------------------------
 // ExSUM, contiguous input
 // ---------------------------------------------------------------------------------------------
-template <int N, bool EE, int COPIES, int U, bool NT>
+template <int N, bool EE, int COPIES, int U, bool NT, bool PF>
 __global__ void __launch_bounds__(BLOCK) k_exsum(const double *__restrict__ a, long long n,
                                                  long long *__restrict__ gacc,
                                                  unsigned *__restrict__ gflags, int ngroups)
@@ -151,18 +151,45 @@ __global__ void __launch_bounds__(BLOCK) k_exsum(const double *__restrict__ a, l
     constexpr long long TILE = (long long)BLOCK * U;
     const long long ntiles = nv / TILE;
 
-    for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        const d2_t *p = v + t * TILE + threadIdx.x;
-        d2_t r[U];
+    if constexpr (!PF) {
+        for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+            const d2_t *p = v + t * TILE + threadIdx.x;
+            d2_t r[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) r[u] = ld2<NT>(p + u * BLOCK);
-        double x[2 * U];
+            for (int u = 0; u < U; ++u) r[u] = ld2<NT>(p + u * BLOCK);
+            double x[2 * U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            x[2 * u] = r[u].x;
-            x[2 * u + 1] = r[u].y;
+            for (int u = 0; u < U; ++u) {
+                x[2 * u] = r[u].x;
+                x[2 * u + 1] = r[u].y;
+            }
+            fpe_absorb<N, EE, COPIES, 2 * U>(fpe, x, 0, col, flags);
         }
-        fpe_absorb<N, EE, COPIES, 2 * U>(fpe, x, 0, col, flags);
+    } else {
+        // register double-buffering: the next tile's loads are in flight while this one is absorbed
+        long long t = blockIdx.x;
+        d2_t r[U];
+        if (t < ntiles) {
+            const d2_t *p = v + t * TILE + threadIdx.x;
+#pragma unroll
+            for (int u = 0; u < U; ++u) r[u] = ld2<NT>(p + u * BLOCK);
+        }
+        while (t < ntiles) {
+            double x[2 * U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                x[2 * u] = r[u].x;
+                x[2 * u + 1] = r[u].y;
+            }
+            const long long tn = t + gridDim.x;
+            if (tn < ntiles) {
+                const d2_t *p = v + tn * TILE + threadIdx.x;
+#pragma unroll
+                for (int u = 0; u < U; ++u) r[u] = ld2<NT>(p + u * BLOCK);
+            }
+            fpe_absorb<N, EE, COPIES, 2 * U>(fpe, x, 0, col, flags);
+            t = tn;
+        }
     }
     // remainder vectors, grid-strided one double2 at a time
     for (long long i = ntiles * TILE + (long long)blockIdx.x * BLOCK + threadIdx.x; i < nv;
@@ -207,7 +234,7 @@ __global__ void __launch_bounds__(BLOCK) k_exsum_strided(const double *__restric
 // ExDOT: TwoProductFMA front-end (ExDOT.Superacc.cl:25-29, :244-253); the rounding error of the
 // product enters the expansion at slot max(N-3,0) like ExDOT.FPE.cl:254
 // ---------------------------------------------------------------------------------------------
-template <int N, bool EE, int COPIES, int U, bool NT>
+template <int N, bool EE, int COPIES, int U, bool NT, bool PF>
 __global__ void __launch_bounds__(BLOCK) k_exdot(const double *__restrict__ a, const double *__restrict__ b,
                                                  long long n, long long *__restrict__ gacc,
                                                  unsigned *__restrict__ gflags, int ngroups)
@@ -228,22 +255,55 @@ __global__ void __launch_bounds__(BLOCK) k_exdot(const double *__restrict__ a, c
     const long long nv = n >> 1;
     constexpr long long TILE = (long long)BLOCK * U;
     const long long ntiles = nv / TILE;
-    for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        const long long base = t * TILE + threadIdx.x;
+    if constexpr (!PF) {
+        for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+            const long long base = t * TILE + threadIdx.x;
+            d2_t ra[U], rb[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                ra[u] = ld2<NT>(va + base + u * BLOCK);
+                rb[u] = ld2<NT>(vb + base + u * BLOCK);
+            }
+            double x[2 * U], e[2 * U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                x[2 * u] = two_prod_safe(ra[u].x, rb[u].x, e[2 * u]);
+                x[2 * u + 1] = two_prod_safe(ra[u].y, rb[u].y, e[2 * u + 1]);
+            }
+            fpe_absorb<N, EE, COPIES, 2 * U>(fpe, x, 0, col, flags);
+            fpe_absorb<N, EE, COPIES, 2 * U>(fpe, e, EFROM, col, flags);
+        }
+    } else {
+        long long t = blockIdx.x;
         d2_t ra[U], rb[U];
+        if (t < ntiles) {
+            const long long base = t * TILE + threadIdx.x;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            ra[u] = ld2<NT>(va + base + u * BLOCK);
-            rb[u] = ld2<NT>(vb + base + u * BLOCK);
+            for (int u = 0; u < U; ++u) {
+                ra[u] = ld2<NT>(va + base + u * BLOCK);
+                rb[u] = ld2<NT>(vb + base + u * BLOCK);
+            }
         }
-        double x[2 * U], e[2 * U];
+        while (t < ntiles) {
+            double x[2 * U], e[2 * U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            x[2 * u] = two_prod_safe(ra[u].x, rb[u].x, e[2 * u]);
-            x[2 * u + 1] = two_prod_safe(ra[u].y, rb[u].y, e[2 * u + 1]);
+            for (int u = 0; u < U; ++u) {
+                x[2 * u] = two_prod_safe(ra[u].x, rb[u].x, e[2 * u]);
+                x[2 * u + 1] = two_prod_safe(ra[u].y, rb[u].y, e[2 * u + 1]);
+            }
+            const long long tn = t + gridDim.x;
+            if (tn < ntiles) {
+                const long long base = tn * TILE + threadIdx.x;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    ra[u] = ld2<NT>(va + base + u * BLOCK);
+                    rb[u] = ld2<NT>(vb + base + u * BLOCK);
+                }
+            }
+            fpe_absorb<N, EE, COPIES, 2 * U>(fpe, x, 0, col, flags);
+            fpe_absorb<N, EE, COPIES, 2 * U>(fpe, e, EFROM, col, flags);
+            t = tn;
         }
-        fpe_absorb<N, EE, COPIES, 2 * U>(fpe, x, 0, col, flags);
-        fpe_absorb<N, EE, COPIES, 2 * U>(fpe, e, EFROM, col, flags);
     }
     for (long long i = ntiles * TILE + (long long)blockIdx.x * BLOCK + threadIdx.x; i < nv;
          i += (long long)gridDim.x * BLOCK) {
@@ -296,7 +356,7 @@ __global__ void __launch_bounds__(BLOCK) k_exdot_strided(const double *__restric
 __global__ void __launch_bounds__(128) k_finalize(long long *sets, int nsets, int set_stride, unsigned *gflags,
                                                   unsigned flags_or, int zero_sets, long long *out)
 {
-    __shared__ long long v[NL];
+    __shared__ FinishShared fs;
     __shared__ unsigned s_fl;
     const int t = threadIdx.x;
     if (t == 0) {
@@ -317,46 +377,65 @@ __global__ void __launch_bounds__(128) k_finalize(long long *sets, int nsets, in
             s += sets[(size_t)g * set_stride + t];
             if (zero_sets) sets[(size_t)g * set_stride + t] = 0;
         }
-        v[t] = s;
+        fs.v[t] = s;
     }
     __syncthreads();  // every input word is read before the first output word is written (out may alias sets)
-    if (t == 0) {
-        long long loc[NL];
-        for (int i = 0; i < NL; ++i) loc[i] = v[i];
-        finish_record(loc, s_fl, out);
-    }
+    finish_record_block(fs, s_fl, out);
 }
 
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
-static inline int grid_for(const Ctx &c, long long work_items, long long per_block)
+static inline int grid_for(const Ctx &c, long long work_items, long long per_block, int blocks_per_cu)
 {
     long long want = (work_items + per_block - 1) / per_block;
-    long long cap = (long long)c.num_cu * c.blocks_per_cu;
+    long long cap = (long long)c.num_cu * blocks_per_cu;
     if (want < 1) want = 1;
     return (int)(want < cap ? want : cap);
+}
+
+template <int N, bool EE, int COPIES, int U, bool NT, bool PF>
+static void run_exsum(Ctx &c, const double *a, long long n, hipStream_t st)
+{
+    int grid = grid_for(c, n, (long long)BLOCK * 2 * U, c.bpc_sum);
+    hipLaunchKernelGGL((k_exsum<N, EE, COPIES, U, NT, PF>), dim3(grid), dim3(BLOCK), 0, st, a, n, c.gacc, c.gflags,
+                       c.ngroups);
 }
 
 template <int N, bool EE>
 static hipError_t launch_exsum(Ctx &c, const double *a, long long n, long long inca, hipStream_t st)
 {
     constexpr int COPIES = (N == 0) ? 16 : 8;
-    constexpr int U = 4;
     if (inca == 1) {
-        int grid = grid_for(c, n, (long long)BLOCK * 2 * U);
-        if (c.nontemporal)
-            hipLaunchKernelGGL((k_exsum<N, EE, COPIES, U, true>), dim3(grid), dim3(BLOCK), 0, st, a, n, c.gacc,
-                               c.gflags, c.ngroups);
-        else
-            hipLaunchKernelGGL((k_exsum<N, EE, COPIES, U, false>), dim3(grid), dim3(BLOCK), 0, st, a, n, c.gacc,
-                               c.gflags, c.ngroups);
+        if constexpr (N == 8 && EE) {
+            // tuning variants of the production kernel, selected with exblas_set_tuning() for A/B runs
+            switch (c.variant) {
+            case 1: run_exsum<N, EE, COPIES, 4, true, false>(c, a, n, st); break;
+            case 2: run_exsum<N, EE, COPIES, 8, true, false>(c, a, n, st); break;
+            case 3: run_exsum<N, EE, COPIES, 2, true, true>(c, a, n, st); break;
+            case 4: run_exsum<N, EE, COPIES, 4, false, true>(c, a, n, st); break;
+            case 5: run_exsum<N, EE, COPIES, 2, true, false>(c, a, n, st); break;
+            case 6: run_exsum<N, EE, COPIES, 8, true, true>(c, a, n, st); break;
+            case 7: run_exsum<N, EE, COPIES, 6, true, true>(c, a, n, st); break;
+            default: run_exsum<N, EE, COPIES, 4, true, true>(c, a, n, st); break;
+            }
+        } else {
+            run_exsum<N, EE, COPIES, 4, true, true>(c, a, n, st);
+        }
     } else {
-        int grid = grid_for(c, n, BLOCK);
+        int grid = grid_for(c, n, BLOCK, c.blocks_per_cu);
         hipLaunchKernelGGL((k_exsum_strided<N, EE, COPIES>), dim3(grid), dim3(BLOCK), 0, st, a, n, inca, c.gacc,
                            c.gflags, c.ngroups);
     }
     return hipGetLastError();
+}
+
+template <int N, bool EE, int COPIES, int U, bool NT, bool PF>
+static void run_exdot(Ctx &c, const double *a, const double *b, long long n, hipStream_t st)
+{
+    int grid = grid_for(c, n, (long long)BLOCK * 2 * U, c.bpc_dot);
+    hipLaunchKernelGGL((k_exdot<N, EE, COPIES, U, NT, PF>), dim3(grid), dim3(BLOCK), 0, st, a, b, n, c.gacc,
+                       c.gflags, c.ngroups);
 }
 
 template <int N, bool EE>
@@ -364,18 +443,24 @@ static hipError_t launch_exdot(Ctx &c, const double *a, long long inca, const do
                                long long n, hipStream_t st)
 {
     constexpr int COPIES = (N == 0) ? 16 : 8;
-    constexpr int U = 2;
     const bool vec = inca == 1 && incb == 1 && (((uintptr_t)a | (uintptr_t)b) & 15u) == 0;
     if (vec) {
-        int grid = grid_for(c, n, (long long)BLOCK * 2 * U);
-        if (c.nontemporal)
-            hipLaunchKernelGGL((k_exdot<N, EE, COPIES, U, true>), dim3(grid), dim3(BLOCK), 0, st, a, b, n, c.gacc,
-                               c.gflags, c.ngroups);
-        else
-            hipLaunchKernelGGL((k_exdot<N, EE, COPIES, U, false>), dim3(grid), dim3(BLOCK), 0, st, a, b, n, c.gacc,
-                               c.gflags, c.ngroups);
+        if constexpr (N == 8 && EE) {
+            switch (c.variant) {
+            case 1: run_exdot<N, EE, COPIES, 2, true, false>(c, a, b, n, st); break;
+            case 2: run_exdot<N, EE, COPIES, 4, true, false>(c, a, b, n, st); break;
+            case 3: run_exdot<N, EE, COPIES, 1, true, true>(c, a, b, n, st); break;
+            case 4: run_exdot<N, EE, COPIES, 2, false, true>(c, a, b, n, st); break;
+            case 5: run_exdot<N, EE, COPIES, 1, true, false>(c, a, b, n, st); break;
+            case 6: run_exdot<N, EE, COPIES, 2, true, true>(c, a, b, n, st); break;
+            case 7: run_exdot<N, EE, COPIES, 3, true, false>(c, a, b, n, st); break;
+            default: run_exdot<N, EE, COPIES, 4, true, true>(c, a, b, n, st); break;
+            }
+        } else {
+            run_exdot<N, EE, COPIES, 4, true, true>(c, a, b, n, st);
+        }
     } else {
-        int grid = grid_for(c, n, BLOCK);
+        int grid = grid_for(c, n, BLOCK, c.blocks_per_cu);
         hipLaunchKernelGGL((k_exdot_strided<N, EE, COPIES>), dim3(grid), dim3(BLOCK), 0, st, a, inca, b, incb, n,
                            c.gacc, c.gflags, c.ngroups);
     }

@@ -74,9 +74,11 @@ Ctx &ctx(int device)
         EXB_CHECK(hipGetDeviceProperties(&prop, device));
         c.num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         c.blocks_per_cu = env_int("EXBLAS_BLOCKS_PER_CU", 8);
+        c.bpc_sum = env_int("EXBLAS_BPC_SUM", 2);
+        c.bpc_dot = env_int("EXBLAS_BPC_DOT", 16);
         c.ngroups = env_int("EXBLAS_NGROUPS", 32);
         if (c.ngroups < 1) c.ngroups = 1;
-        c.nontemporal = env_int("EXBLAS_NT", 1) != 0;
+        c.variant = env_int("EXBLAS_VARIANT", 0);
         EXB_CHECK(hipMalloc(&c.gacc, sizeof(long long) * NL * c.ngroups));
         EXB_CHECK(hipMemset(c.gacc, 0, sizeof(long long) * NL * c.ngroups));
         EXB_CHECK(hipMalloc(&c.gflags, 64));
@@ -243,6 +245,23 @@ int exblas_hip_device_count(void)
 const char *exblas_hip_version(void) { return "exblas-hip 0.1 (gfx950)"; }
 
 void exblas_set_round_mode(int mode) { g_round_mode = mode ? 1 : 0; }
+
+int exblas_set_tuning(int blocks_per_cu, int ngroups, int variant)
+{
+    Ctx &c = ctx(-1);
+    std::lock_guard<std::mutex> lk(c.mu);
+    if (blocks_per_cu > 0) c.blocks_per_cu = c.bpc_sum = c.bpc_dot = blocks_per_cu;
+    if (ngroups > 0 && ngroups != c.ngroups) {
+        EXB_CHECK(hipDeviceSynchronize());
+        EXB_CHECK(hipFree(c.gacc));
+        c.ngroups = ngroups;
+        EXB_CHECK(hipMalloc(&c.gacc, sizeof(long long) * NL * c.ngroups));
+        EXB_CHECK(hipMemset(c.gacc, 0, sizeof(long long) * NL * c.ngroups));
+        EXB_CHECK(hipDeviceSynchronize());
+    }
+    if (variant >= 0) c.variant = variant;
+    return 0;
+}
 int exblas_get_round_mode(void) { return round_mode(); }
 
 int exblas_exsum_accumulate_dev(const double *d_a, int64_t n, int64_t inca, int fpe, int early_exit, void *stream)

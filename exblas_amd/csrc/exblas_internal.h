@@ -12,9 +12,12 @@ namespace exb {
 struct Ctx {
     int device = -1;
     int num_cu = 256;
-    int blocks_per_cu = 8;   // EXBLAS_BLOCKS_PER_CU
+    int blocks_per_cu = 8;   // EXBLAS_BLOCKS_PER_CU: generic cap of resident blocks per CU
+    // Measured on MI355X (tools/tune.py, n = 2^28): the one-stream ExSUM kernel is fastest with FEW fat
+    // blocks (2 per CU: 7.15 TB/s vs 6.46 at 8), the two-stream ExDOT kernel with many (16-32 per CU).
+    int bpc_sum = 2, bpc_dot = 16;
     int ngroups = 32;        // EXBLAS_NGROUPS: global group accumulators the blocks add into
-    bool nontemporal = true; // EXBLAS_NT
+    int variant = 0;         // tuning variant of the production kernels (exblas_set_tuning)
     long long *gacc = nullptr;   // [ngroups][NL] int64, zero between calls
     unsigned *gflags = nullptr;  // non-finite input flags, zero between calls
     // host-pointer API staging

@@ -55,6 +55,9 @@ extern "C" {
 int exblas_hip_init(int device);
 int exblas_hip_device_count(void);
 const char *exblas_hip_version(void);
+/* Launch-geometry knobs for A/B measurements (<= 0 / < 0 leave a value unchanged): resident blocks per CU
+ * of the streaming kernels, number of global group accumulators, kernel variant (0 = production). */
+int exblas_set_tuning(int blocks_per_cu, int ngroups, int variant);
 /* 0 = exact, 1 = reference; overrides EXBLAS_ROUND for the host-pointer API */
 void exblas_set_round_mode(int mode);
 int exblas_get_round_mode(void);
