@@ -30,8 +30,11 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--prewarm-ms", type=float, default=400.0,
+                    help="untimed clock ramp-up before the W warmup steps: the same kernel run back to back "
+                         "(the chip needs a few hundred ms of load to reach its sustained clocks)")
     ap.add_argument("--op", default="exsum", choices=["exsum", "exdot"])
     ap.add_argument("--log2n", type=int, default=28, help="elements per GPU = 2^log2n")
     ap.add_argument("--kind", default="ill_cond")
@@ -46,7 +49,7 @@ def parse():
     return ap.parse_args()
 
 
-def timed_steps(ex, torch, dist, op, tensors, fpe, ee, steps, warmup, world, rec):
+def timed_steps(ex, torch, dist, op, tensors, fpe, ee, steps, warmup, world, rec, prewarm_ms=0.0):
     """Returns (wall seconds for `steps` steps, mean ms of the streaming kernel alone)."""
     def one_step(e0=None, e1=None):
         if e0 is not None:
@@ -62,6 +65,11 @@ def timed_steps(ex, torch, dist, op, tensors, fpe, ee, steps, warmup, world, rec
             ex.allreduce_record(rec)
             ex.finalize_dev(rec[ex.OUT_DIGITS:ex.OUT_DIGITS + ex.SET_WORDS], out=rec)
 
+    t_pre = time.perf_counter()
+    while (time.perf_counter() - t_pre) * 1e3 < prewarm_ms:
+        for _ in range(20):
+            one_step()
+        torch.cuda.synchronize()
     for _ in range(warmup):
         one_step()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
@@ -145,7 +153,8 @@ def main():
     rec = ex.new_record_buffer()
     bytes_per_elem = 8 if args.op == "exsum" else 16
 
-    dt, kms = timed_steps(ex, torch, dist, args.op, tensors, args.fpe, ee, args.steps, args.warmup, world, rec)
+    dt, kms = timed_steps(ex, torch, dist, args.op, tensors, args.fpe, ee, args.steps, args.warmup, world, rec,
+                          args.prewarm_ms)
     if world > 1:
         t = torch.tensor([dt, kms], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -169,7 +178,8 @@ def main():
         # ExDOT on the same shape (BASELINE config 2), reported beside the headline number
         y = ex.gen_dev(args.kind, n, 2, args.p0, args.p1, first=first, count=n, n_total=n_total)
         rec2 = ex.new_record_buffer()
-        ddt, dkms = timed_steps(ex, torch, dist, "exdot", [x, y], args.fpe, ee, args.steps, args.warmup, world, rec2)
+        ddt, dkms = timed_steps(ex, torch, dist, "exdot", [x, y], args.fpe, ee, args.steps, args.warmup, world, rec2,
+                                args.prewarm_ms)
         if world > 1:
             t = torch.tensor([ddt, dkms], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)

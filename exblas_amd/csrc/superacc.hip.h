@@ -267,74 +267,89 @@ __device__ inline void finish_record(long long *v, unsigned flags, long long *ou
 }
 
 // ---------------------------------------------------------------------------------------------
-// The same final step done cooperatively by one workgroup (>= 72 threads, all must call): carry
-// propagation as lane-parallel passes (a carry moves one digit per pass; sums of < 2^31 chunks
-// settle in 2-3 passes, the loop runs until no digit is out of range), leading-digit / sticky
-// searches as LDS min/max reductions, canonical limbs one per thread.  ~10x faster than the
-// single-thread version above, which it must (and is tested to) match bit for bit.
+// The same final step done cooperatively: GROUP consecutive threads of a workgroup (64 = one wave,
+// or the whole block) work on one FinishShared; several groups of a block may each finish their own
+// accumulator at the same time, so every barrier below is block-wide and block-uniform (ALL threads
+// of the block must call).  Carry propagation runs as lane-parallel passes (a carry moves one digit
+// per pass; sums of < 2^31 chunks settle in 2-3 passes, the loop runs until no digit of any group is
+// out of range), leading-digit / sticky searches are LDS min/max reductions, canonical limbs are cut
+// one per thread.  Must (and is tested to) match the single-thread version above bit for bit.
 // ---------------------------------------------------------------------------------------------
 struct FinishShared {
     long long v[NL];        // in: raw limb sums; out: normalised digits (top limb signed)
     long long canon[CANON];
     unsigned mag[NL];
     int z, top, ci, cz;
+    unsigned long long ex;  // out: bits of the correctly rounded double
+    double rf;              // out: reference-compatible rounding
 };
 
-__device__ inline void finish_record_block(FinishShared &s, unsigned flags, long long *out)
+template <int GROUP>
+__device__ inline void finish_core(FinishShared &s, const int lane /* 0..GROUP-1 */, const unsigned flags)
 {
-    const int t = threadIdx.x;
-    if (t == 0) { s.z = NL; s.top = -1; s.ci = -1; s.cz = CANON; }
+    if (lane == 0) { s.z = NL; s.top = -1; s.ci = -1; s.cz = CANON; }
     // ---- carry propagation, all digits at once per pass ----
+    constexpr int PER = (NL + GROUP - 1) / GROUP;
     for (int pass = 0; pass < 2 * NL; ++pass) {
-        long long lo = 0, cin = 0;
-        if (t < NL) {
-            lo = (t < NL - 1) ? (s.v[t] & 0xffffffffll) : s.v[t];
-            cin = (t > 0) ? (s.v[t - 1] >> 32) : 0;  // arithmetic: signed carry of the digit below
+        long long lo[PER], cin[PER];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int t = lane + k * GROUP;
+            lo[k] = cin[k] = 0;
+            if (t < NL) {
+                lo[k] = (t < NL - 1) ? (s.v[t] & 0xffffffffll) : s.v[t];
+                cin[k] = (t > 0) ? (s.v[t - 1] >> 32) : 0;  // arithmetic: signed carry of the digit below
+            }
         }
         __syncthreads();
         bool pending = false;
-        if (t < NL) {
-            const long long nv = lo + cin;
-            s.v[t] = nv;
-            pending = (t < NL - 1) && ((nv >> 32) != 0);
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int t = lane + k * GROUP;
+            if (t < NL) {
+                const long long nv = lo[k] + cin[k];
+                s.v[t] = nv;
+                pending |= (t < NL - 1) && ((nv >> 32) != 0);
+            }
         }
         if (!__syncthreads_or(pending)) break;
     }
     // ---- magnitude digits, leading / lowest non-zero digit ----
     const bool neg = s.v[NL - 1] < 0;
-    unsigned d = 0;
-    if (t < NL) {
-        d = (unsigned)s.v[t];
-        if (d) atomicMin(&s.z, t);
-    }
+    for (int t = lane; t < NL; t += GROUP)
+        if ((unsigned)s.v[t]) atomicMin(&s.z, t);
     __syncthreads();
-    if (t < NL) {
+    {
         const int z = s.z;
-        const unsigned m = !neg ? d : (t < z ? 0u : (t == z ? (0u - d) : ~d));
-        s.mag[t] = m;
-        if (m) atomicMax(&s.top, t);
+        for (int t = lane; t < NL; t += GROUP) {
+            const unsigned d = (unsigned)s.v[t];
+            const unsigned m = !neg ? d : (t < z ? 0u : (t == z ? (0u - d) : ~d));
+            s.mag[t] = m;
+            if (m) atomicMax(&s.top, t);
+        }
     }
     // ---- canonical limbs, one per thread ----
-    long long cj = 0;
-    if (t < CANON - 1) cj = digits_field52(s.v, CANON_DIGITS * t - 18);
-    if (t == CANON - 1) {
-        const int o = CANON_DIGITS * (CANON - 1) - 18;
-        const int q = o >> 5, r = o & 31;
-        auto dig = [&](int i) -> unsigned long long {
-            if (i >= NL - 1) {
-                const long long top = s.v[NL - 1];
-                const int k = i - (NL - 1);
-                if (k == 0) return (unsigned long long)(unsigned)top;
-                if (k == 1) return (unsigned long long)(unsigned)(top >> 32);
-                return (top < 0) ? 0xffffffffull : 0ull;
-            }
-            return (unsigned long long)(unsigned)s.v[i];
-        };
-        const unsigned long long lo = dig(q) | (dig(q + 1) << 32);
-        const unsigned long long hi = dig(q + 2) | (dig(q + 3) << 32);
-        cj = (long long)(r ? ((lo >> r) | (hi << (64 - r))) : lo);
-    }
-    if (t < CANON) {
+    for (int t = lane; t < CANON; t += GROUP) {
+        long long cj;
+        if (t < CANON - 1) {
+            cj = digits_field52(s.v, CANON_DIGITS * t - 18);
+        } else {
+            const int o = CANON_DIGITS * (CANON - 1) - 18;
+            const int q = o >> 5, r = o & 31;
+            auto dig = [&](int i) -> unsigned long long {
+                if (i >= NL - 1) {
+                    const long long top = s.v[NL - 1];
+                    const int k = i - (NL - 1);
+                    if (k == 0) return (unsigned long long)(unsigned)top;
+                    if (k == 1) return (unsigned long long)(unsigned)(top >> 32);
+                    return (top < 0) ? 0xffffffffull : 0ull;
+                }
+                return (unsigned long long)(unsigned)s.v[i];
+            };
+            const unsigned long long lo = dig(q) | (dig(q + 1) << 32);
+            const unsigned long long hi = dig(q + 2) | (dig(q + 3) << 32);
+            cj = (long long)(r ? ((lo >> r) | (hi << (64 - r))) : lo);
+        }
         s.canon[t] = cj;
         const long long mask = (1ll << CANON_DIGITS) - 1;
         // leading word of Superaccumulator::Round: zeros are skipped, and for a negative value
@@ -343,8 +358,8 @@ __device__ inline void finish_record_block(FinishShared &s, unsigned flags, long
         if (cj != 0) atomicMin(&s.cz, t);
     }
     __syncthreads();
-    // ---- the two roundings (thread 0) ----
-    if (t == 0) {
+    // ---- the two roundings (lane 0) ----
+    if (lane == 0) {
         unsigned long long ex = 0ull;
         const int tp = s.top;
         const unsigned long long sign = neg ? 0x8000000000000000ull : 0ull;
@@ -403,8 +418,21 @@ __device__ inline void finish_record_block(FinishShared &s, unsigned flags, long
                      : ((flags & FLAG_NINF) ? 0xfff0000000000000ull : 0x7ff0000000000000ull);
             rf = __longlong_as_double((long long)ex);
         }
-        out[OUT_EXACT] = (long long)ex;
-        out[OUT_REFMODE] = __double_as_longlong(rf);
+        s.ex = ex;
+        s.rf = rf;
+    }
+    __syncthreads();
+}
+
+// whole-block version writing the full record (blockDim.x threads cooperate, >= 64)
+template <int GROUP>
+__device__ inline void finish_record_block(FinishShared &s, unsigned flags, long long *out)
+{
+    const int t = threadIdx.x;
+    finish_core<GROUP>(s, t, flags);
+    if (t == 0) {
+        out[OUT_EXACT] = (long long)s.ex;
+        out[OUT_REFMODE] = __double_as_longlong(s.rf);
         out[OUT_FLAGS] = (long long)flags;
         out[3] = 0;
         out[OUT_FLAGCNT + 0] = (flags & FLAG_PINF) ? 1 : 0;
@@ -412,8 +440,8 @@ __device__ inline void finish_record_block(FinishShared &s, unsigned flags, long
         out[OUT_FLAGCNT + 2] = (flags & FLAG_NAN) ? 1 : 0;
         out[OUT_FLAGCNT + 3] = 0;
     }
-    if (t < CANON) out[OUT_CANON + t] = s.canon[t];
-    if (t < NL) out[OUT_DIGITS + t] = s.v[t];
+    for (int j = t; j < CANON; j += GROUP) out[OUT_CANON + j] = s.canon[j];
+    for (int j = t; j < NL; j += GROUP) out[OUT_DIGITS + j] = s.v[j];
 }
 
 }  // namespace exb
