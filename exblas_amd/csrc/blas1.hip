@@ -13,95 +13,28 @@
 //     ONCE, re-cuts into the reference's canonical limbs and rounds.  No inter-workgroup reads inside a
 //     launch (the reference's ExSUMComplete races on that).
 #include "superacc.hip.h"
+#include "fpe.hip.h"
 #include "exblas_internal.h"
 
 namespace exb {
 
-typedef double d2_t __attribute__((ext_vector_type(2)));
-
-template <bool NT>
-__device__ __forceinline__ d2_t ld2(const d2_t *p)
-{
-    if constexpr (NT) return __builtin_nontemporal_load(p);
-    else return *p;
-}
-
 constexpr int BLOCK = 256;
 constexpr int WAVES = BLOCK / 64;
 
-// biased exponent field of a double, and the guard threshold 2^1000 (see fpe_absorb)
-__device__ __forceinline__ unsigned expo_field(double x) { return ((unsigned)__double2hiint(x) >> 20) & 0x7ffu; }
-constexpr unsigned BIG_EXPO = 1023u + 1000u;
-
-// ---------------------------------------------------------------------------------------------
-// per-lane floating-point expansion
-// ---------------------------------------------------------------------------------------------
+// blas1 sinks everything into the wave's LDS accumulator column
 template <int N, bool EE, int COPIES, int CNT>
 __device__ __forceinline__ void fpe_absorb(double (&a)[N > 0 ? N : 1], double (&x)[CNT], int from,
                                            long long *col, unsigned &flags)
 {
-    if constexpr (N == 0) {
-#pragma unroll
-        for (int j = 0; j < CNT; ++j) lds_add<COPIES>(col, x[j], flags);
-    } else {
-        if (from == 0) {
-            // Range guard (one wave-uniform test per tile): TwoSum is only error-free while a + x stays
-            // finite.  Elements of magnitude >= 2^1000 and Inf/NaN bypass the expansion and go straight to
-            // the integer accumulator (which holds them exactly, resp. classifies them), and a[0] is spilled
-            // once it reaches 2^1000 -- so a[0] never exceeds (1 + CNT) * 2^1000 and cannot overflow.  The
-            // reference has no such guard (ExSUM.FPE.hpp:408 "TODO ... Inf/Overflow/NaN").
-            unsigned mx = expo_field(a[0]);
-#pragma unroll
-            for (int j = 0; j < CNT; ++j) mx = max(mx, expo_field(x[j]));
-            if (__any(mx >= BIG_EXPO)) {
-#pragma unroll
-                for (int j = 0; j < CNT; ++j)
-                    if (expo_field(x[j]) >= BIG_EXPO) {
-                        lds_add<COPIES>(col, x[j], flags);
-                        x[j] = 0.0;
-                    }
-                if (expo_field(a[0]) >= BIG_EXPO) {
-                    lds_add<COPIES>(col, a[0], flags);
-                    a[0] = 0.0;
-                }
-            }
-        }
-        bool live = true;
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
-            if (i >= from && live) {
-#pragma unroll
-                for (int j = 0; j < CNT; ++j) {
-                    double s;
-                    a[i] = two_sum(a[i], x[j], s);
-                    x[j] = s;
-                }
-                if (EE && i > from) {
-                    bool nz = false;
-#pragma unroll
-                    for (int j = 0; j < CNT; ++j) nz |= (x[j] != 0.0);
-                    live = __any(nz);  // wave-uniform
-                }
-            }
-        }
-        if (live) {
-#pragma unroll
-            for (int j = 0; j < CNT; ++j)
-                if (x[j] != 0.0) lds_add<COPIES>(col, x[j], flags);
-        }
-    }
+    LdsSink<COPIES> sink{col, flags};
+    fpe_absorb_sink<N, EE, CNT>(a, x, from, sink);
 }
 
 template <int N, int COPIES>
 __device__ __forceinline__ void fpe_flush(double (&a)[N > 0 ? N : 1], long long *col, unsigned &flags)
 {
-    if constexpr (N > 0) {
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
-            if (a[i] != 0.0) lds_add<COPIES>(col, a[i], flags);
-            a[i] = 0.0;
-        }
-    }
+    LdsSink<COPIES> sink{col, flags};
+    fpe_flush_sink<N>(a, sink);
 }
 
 // block epilogue: columns -> one limb vector -> global group accumulator

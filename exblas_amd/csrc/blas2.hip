@@ -1,9 +1,416 @@
-// blas2.hip -- ExGEMV (placeholder until the kernels land)
+// blas2.hip -- ExGEMV for gfx950, column-major A (the reference's layout, tests/test.exgemv.gpu.cpp:160).
+//
+// Replaces the reference's OpenCL kernels gemv / gemvT (src/gpu/blas/blas2/ExGEMV.Superacc.cl:192-392,
+// ExGEMV.FPE.cl:199/:382, ExGEMV.FPE.EX.*.cl) and dgemv/dgemvT (DGEMV.cl:13,:86) -- behaviour only:
+//   y_i = Round( sum_k A(i,k) * fl(alpha * x_k)  (+)  beta * y_i ),   every y_i correctly rounded.
+// The reference gives one work-item per output row a private 39-limb accumulator in *global* memory and
+// needs all of x in LDS (256 KiB at n = 32768: it cannot run BASELINE config 4).  Here:
+//   'N'  lanes own ROWS (two adjacent rows per lane, one 16-byte load per column, 1 KiB per wave-load);
+//        each row has its expansion in registers; columns are split over blockIdx.y so that ~2K workgroups
+//        stream A once; the per-(row, k-split) expansions are written out and a second kernel folds them,
+//        the row's rare global-memory spill accumulator and beta*y into an LDS accumulator and rounds.
+//   'T'  one workgroup per output: a column of A is a contiguous vector, so this is the ExDOT kernel
+//        with the final carry-propagate + round done inside the workgroup.
+#include "superacc.hip.h"
+#include "fpe.hip.h"
 #include "exblas_internal.h"
+
 namespace exb {
-hipError_t exgemv_dispatch(Ctx &, char, int, int, double, const double *, int, const double *, int, double,
-                           double *, int, int, int, int, hipStream_t)
+
+constexpr int GV_BLOCK = 256;
+constexpr int GV_WAVES = GV_BLOCK / 64;
+constexpr int GV_KC = 1024;  // columns of x staged in LDS at a time (8 KiB)
+
+// ---------------------------------------------------------------------------------------------
+// 'N', expansion path: two rows per lane
+// ---------------------------------------------------------------------------------------------
+template <int N, bool EE, bool VEC>
+__global__ void __launch_bounds__(GV_BLOCK) k_gemvN_fpe(int m, int n, double alpha, const double *__restrict__ a,
+                                                        long long lda, const double *__restrict__ x, long long incx,
+                                                        int kper, double *__restrict__ part,
+                                                        long long *__restrict__ ws)
 {
-    return hipErrorNotSupported;
+    __shared__ double xs[GV_KC];
+    const int tid = threadIdx.x;
+    const long long r0 = ((long long)blockIdx.x * GV_BLOCK + tid) * 2;
+    const int ks = blockIdx.y, KS = gridDim.y;
+    const int k0 = ks * kper, k1 = min(n, k0 + kper);
+    const bool v0 = r0 < m, v1 = r0 + 1 < m;
+    constexpr int EFROM = (N >= 3) ? N - 3 : 0;
+    double f0[N], f1[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) f0[i] = f1[i] = 0.0;
+    GlobalSink s0{ws + (v0 ? r0 : 0) * SET_WORDS}, s1{ws + (v1 ? r0 + 1 : 0) * SET_WORDS};
+
+    for (int kc = k0; kc < k1; kc += GV_KC) {
+        const int cnt = min(GV_KC, k1 - kc);
+        __syncthreads();
+        for (int i = tid; i < cnt; i += GV_BLOCK) xs[i] = alpha * x[(long long)(kc + i) * incx];  // rounded fold of alpha
+        __syncthreads();
+        if (v0) {
+            const double *col = a + r0 + lda * kc;
+            int k = 0;
+            constexpr int U = 4;
+            for (; k + U <= cnt; k += U) {
+                double ax[U], ay[U];
+#pragma unroll
+                for (int j = 0; j < U; ++j) {
+                    if constexpr (VEC) {
+                        const d2_t r = ld2<true>((const d2_t *)(col + lda * (k + j)));
+                        ax[j] = r.x;
+                        ay[j] = r.y;
+                    } else {
+                        ax[j] = col[lda * (k + j)];
+                        ay[j] = v1 ? col[lda * (k + j) + 1] : 0.0;
+                    }
+                }
+                double p[U], e[U];
+#pragma unroll
+                for (int j = 0; j < U; ++j) p[j] = two_prod_safe(ax[j], xs[k + j], e[j]);
+                fpe_absorb_sink<N, EE, U>(f0, p, 0, s0);
+                fpe_absorb_sink<N, EE, U>(f0, e, EFROM, s0);
+#pragma unroll
+                for (int j = 0; j < U; ++j) p[j] = two_prod_safe(ay[j], xs[k + j], e[j]);
+                fpe_absorb_sink<N, EE, U>(f1, p, 0, s1);
+                fpe_absorb_sink<N, EE, U>(f1, e, EFROM, s1);
+            }
+            for (; k < cnt; ++k) {
+                const double ax = col[lda * k], ay = v1 ? col[lda * k + 1] : 0.0;
+                double p[1], e[1];
+                p[0] = two_prod_safe(ax, xs[k], e[0]);
+                fpe_absorb_sink<N, false, 1>(f0, p, 0, s0);
+                fpe_absorb_sink<N, false, 1>(f0, e, EFROM, s0);
+                p[0] = two_prod_safe(ay, xs[k], e[0]);
+                fpe_absorb_sink<N, false, 1>(f1, p, 0, s1);
+                fpe_absorb_sink<N, false, 1>(f1, e, EFROM, s1);
+            }
+        }
+    }
+    if (v0) {
+        double *o = part + ((size_t)r0 * KS + ks) * N;
+#pragma unroll
+        for (int i = 0; i < N; ++i) o[i] = f0[i];
+    }
+    if (v1) {
+        double *o = part + ((size_t)(r0 + 1) * KS + ks) * N;
+#pragma unroll
+        for (int i = 0; i < N; ++i) o[i] = f1[i];
+    }
 }
+
+// ---------------------------------------------------------------------------------------------
+// 'N', superaccumulators only (fpe == 0): 64 rows per workgroup, one private LDS column per row
+// (limb-major [limb][row]: the bank depends on the lane only, so the data-dependent limb index never
+// conflicts); the four waves take every fourth column.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(GV_BLOCK) k_gemvN_sa(int m, int n, double alpha, const double *__restrict__ a,
+                                                       long long lda, const double *__restrict__ x, long long incx,
+                                                       int kper, long long *__restrict__ ws)
+{
+    __shared__ long long acc[NL * 64];
+    __shared__ double xs[GV_KC];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < NL * 64; i += GV_BLOCK) acc[i] = 0;
+    const long long row = (long long)blockIdx.x * 64 + lane;
+    const bool valid = row < m;
+    const int k0 = blockIdx.y * kper, k1 = min(n, k0 + kper);
+    unsigned flags = 0;
+    LdsSink<64> sink{acc + lane, flags};
+    for (int kc = k0; kc < k1; kc += GV_KC) {
+        const int cnt = min(GV_KC, k1 - kc);
+        __syncthreads();
+        for (int i = tid; i < cnt; i += GV_BLOCK) xs[i] = alpha * x[(long long)(kc + i) * incx];
+        __syncthreads();
+        if (valid) {
+            const double *col = a + row + lda * kc;
+            for (int k = wave; k < cnt; k += GV_WAVES) {
+                double e, p = two_prod_safe(col[lda * k], xs[k], e);
+                sink.add(p);
+                if (e != 0.0) sink.add(e);
+            }
+        }
+    }
+    __syncthreads();
+    // spill the 64 x 68 limbs into the rows' global accumulators (other k-splits add to the same rows)
+    for (int i = tid; i < NL * 64; i += GV_BLOCK) {
+        const int l = i >> 6, r = i & 63;
+        const long long v = acc[i];
+        const long long grow = (long long)blockIdx.x * 64 + r;
+        if (v != 0 && grow < m) atomicAdd((unsigned long long *)&ws[grow * SET_WORDS + l], (unsigned long long)v);
+    }
+    if (valid && flags) {
+        for (int k = 0; k < 3; ++k)
+            if (flags & (1u << k)) atomicAdd((unsigned long long *)&ws[row * SET_WORDS + NL + k], 1ull);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 'N', second kernel: one wave per row folds the row's partial expansions, its global spill
+// accumulator and beta*y (ExGEMV.Superacc.cl:258-291: beta == 0 ignores y, beta == 1 adds y
+// exactly, otherwise TwoProductFMA(beta, y)) and rounds once.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(GV_BLOCK) k_gemv_finish(int rows, int nvals, const double *__restrict__ part,
+                                                          const long long *__restrict__ ws, double beta,
+                                                          double *__restrict__ y, long long incy, int round_mode)
+{
+    __shared__ FinishShared fs[GV_WAVES];
+    __shared__ unsigned fl[GV_WAVES];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const long long row = (long long)blockIdx.x * GV_WAVES + w;
+    const bool valid = row < rows;
+    for (int t = lane; t < NL; t += 64) fs[w].v[t] = 0;
+    if (lane == 0) fl[w] = 0;
+    __syncthreads();
+    if (valid) {
+        unsigned flags = 0;
+        LdsSink<1> sink{fs[w].v, flags};
+        const double *pr = part + (size_t)row * nvals;
+        for (int i = lane; i < nvals; i += 64) {
+            const double v = pr[i];
+            if (v != 0.0) sink.add(v);
+        }
+        if (lane == 0 && beta != 0.0) {
+            const double yv = y[row * incy];
+            if (beta == 1.0) {
+                sink.add(yv);
+            } else {
+                double e, p = two_prod_safe(beta, yv, e);
+                sink.add(p);
+                if (e != 0.0) sink.add(e);
+            }
+        }
+        const long long *g = ws + row * SET_WORDS;
+        for (int t = lane; t < NL; t += 64) {
+            const long long v = g[t];
+            if (v) atomicAdd((unsigned long long *)&fs[w].v[t], (unsigned long long)v);
+        }
+        if (lane < 3 && g[NL + lane] != 0) flags |= 1u << lane;
+        if (flags) atomicOr(&fl[w], flags);
+    }
+    __syncthreads();
+    finish_core<64>(fs[w], lane, fl[w]);
+    if (valid && lane == 0) y[row * incy] = round_mode ? fs[w].rf : __longlong_as_double((long long)fs[w].ex);
+}
+
+// ---------------------------------------------------------------------------------------------
+// 'T': y_j = Round(sum_i A(i,j) * fl(alpha*x_i) (+) beta*y_j); column j is contiguous -> ExDOT per workgroup
+// ---------------------------------------------------------------------------------------------
+template <int N, bool EE, int COPIES>
+__global__ void __launch_bounds__(GV_BLOCK) k_gemvT(int m, double alpha, const double *__restrict__ a, long long lda,
+                                                    const double *__restrict__ x, long long incx, double beta,
+                                                    double *__restrict__ y, long long incy, int round_mode)
+{
+    __shared__ long long s_acc[GV_WAVES * NL * COPIES];
+    __shared__ FinishShared fs;
+    __shared__ unsigned s_flags;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < GV_WAVES * NL * COPIES; i += GV_BLOCK) s_acc[i] = 0;
+    if (tid == 0) s_flags = 0;
+    __syncthreads();
+    const long long j = blockIdx.x;
+    const double *col = a + lda * j;
+    unsigned flags = 0;
+    LdsSink<COPIES> sink{s_acc + wave * NL * COPIES + (lane & (COPIES - 1)), flags};
+    constexpr int EFROM = (N >= 3) ? N - 3 : 0;
+    double f[N > 0 ? N : 1];
+#pragma unroll
+    for (int i = 0; i < (N > 0 ? N : 1); ++i) f[i] = 0.0;
+
+    const bool vec = incx == 1 && ((((uintptr_t)col) | ((uintptr_t)x)) & 15u) == 0;
+    long long done = 0;
+    if (vec) {
+        constexpr int U = 2;
+        const d2_t *va = (const d2_t *)col, *vx = (const d2_t *)x;
+        const long long nv = m >> 1, tile = (long long)GV_BLOCK * U, ntiles = nv / tile;
+        for (long long t = 0; t < ntiles; ++t) {
+            const long long base = t * tile + tid;
+            d2_t ra[U], rx[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                ra[u] = ld2<true>(va + base + u * GV_BLOCK);
+                rx[u] = vx[base + u * GV_BLOCK];  // x is re-read by every workgroup: keep it cacheable
+            }
+            double p[2 * U], e[2 * U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                p[2 * u] = two_prod_safe(ra[u].x, alpha * rx[u].x, e[2 * u]);
+                p[2 * u + 1] = two_prod_safe(ra[u].y, alpha * rx[u].y, e[2 * u + 1]);
+            }
+            fpe_absorb_sink<N, EE, 2 * U>(f, p, 0, sink);
+            fpe_absorb_sink<N, EE, 2 * U>(f, e, EFROM, sink);
+        }
+        done = ntiles * tile * 2;
+    }
+    for (long long i = done + tid; i < m; i += GV_BLOCK) {
+        double p[1], e[1];
+        p[0] = two_prod_safe(col[i], alpha * x[i * incx], e[0]);
+        fpe_absorb_sink<N, false, 1>(f, p, 0, sink);
+        fpe_absorb_sink<N, false, 1>(f, e, EFROM, sink);
+    }
+    fpe_flush_sink<N>(f, sink);
+    if (tid == 0 && beta != 0.0) {
+        const double yv = y[j * incy];
+        if (beta == 1.0) {
+            sink.add(yv);
+        } else {
+            double e, p = two_prod_safe(beta, yv, e);
+            sink.add(p);
+            if (e != 0.0) sink.add(e);
+        }
+    }
+    if (flags) atomicOr(&s_flags, flags);
+    __syncthreads();
+    for (int l = tid; l < NL; l += GV_BLOCK) {
+        long long sum = 0;
+#pragma unroll
+        for (int w = 0; w < GV_WAVES; ++w)
+#pragma unroll
+            for (int c = 0; c < COPIES; ++c) sum += s_acc[(w * NL + l) * COPIES + c];
+        fs.v[l] = sum;
+    }
+    __syncthreads();
+    finish_core<GV_BLOCK>(fs, tid, s_flags);
+    if (tid == 0) y[j * incy] = round_mode ? fs.rf : __longlong_as_double((long long)fs.ex);
+}
+
+// ---------------------------------------------------------------------------------------------
+// fpe == 1: the plain, NON-reproducible fp64 GEMV the reference ships as its baseline (DGEMV.cl)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(GV_BLOCK) k_dgemvN(int m, int n, double alpha, const double *__restrict__ a,
+                                                     long long lda, const double *__restrict__ x, long long incx,
+                                                     double beta, double *__restrict__ y, long long incy)
+{
+    const long long row = (long long)blockIdx.x * GV_BLOCK + threadIdx.x;
+    if (row >= m) return;
+    double sum = 0.0;
+    for (int k = 0; k < n; ++k) sum += alpha * a[row + lda * k] * x[(long long)k * incx];
+    y[row * incy] = (beta == 0.0) ? sum : sum + beta * y[row * incy];
+}
+
+__global__ void __launch_bounds__(64) k_dgemvT(int m, double alpha, const double *__restrict__ a, long long lda,
+                                               const double *__restrict__ x, long long incx, double beta,
+                                               double *__restrict__ y, long long incy)
+{
+    const long long j = blockIdx.x;
+    double sum = 0.0;
+    for (long long i = threadIdx.x; i < m; i += 64) sum += alpha * a[lda * j + i] * x[i * incx];
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off);
+    if (threadIdx.x == 0) y[j * incy] = (beta == 0.0) ? sum : sum + beta * y[j * incy];
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+template <int N, bool EE>
+static hipError_t gemvN_fpe(Ctx &c, int m, int n, double alpha, const double *a, int lda, const double *x, int incx,
+                            double beta, double *y, int incy, int round_mode, hipStream_t st)
+{
+    const int gx = (m + 2 * GV_BLOCK - 1) / (2 * GV_BLOCK);
+    int KS = (c.num_cu * 8 + gx - 1) / gx;
+    const int max_ks = (n + 63) / 64;
+    if (KS > max_ks) KS = max_ks;
+    if (KS > 64) KS = 64;
+    if (KS < 1) KS = 1;
+    int kper = (n + KS - 1) / KS;
+    kper = (kper + 3) & ~3;
+    KS = (n + kper - 1) / kper;
+    const size_t ws_bytes = (size_t)m * SET_WORDS * sizeof(long long);
+    const size_t part_bytes = (size_t)m * KS * N * sizeof(double);
+    char *base = (char *)workspace(c, ws_bytes + part_bytes);
+    long long *ws = (long long *)base;
+    double *part = (double *)(base + ws_bytes);
+    hipError_t e = hipMemsetAsync(ws, 0, ws_bytes, st);
+    if (e != hipSuccess) return e;
+    const bool vec = (m % 2 == 0) && (lda % 2 == 0) && (((uintptr_t)a) & 15u) == 0;
+    dim3 grid(gx, KS);
+    if (vec)
+        hipLaunchKernelGGL((k_gemvN_fpe<N, EE, true>), grid, dim3(GV_BLOCK), 0, st, m, n, alpha, a, (long long)lda, x,
+                           (long long)incx, kper, part, ws);
+    else
+        hipLaunchKernelGGL((k_gemvN_fpe<N, EE, false>), grid, dim3(GV_BLOCK), 0, st, m, n, alpha, a, (long long)lda, x,
+                           (long long)incx, kper, part, ws);
+    hipLaunchKernelGGL(k_gemv_finish, dim3((m + GV_WAVES - 1) / GV_WAVES), dim3(GV_BLOCK), 0, st, m, KS * N, part, ws,
+                       beta, y, (long long)incy, round_mode);
+    return hipGetLastError();
+}
+
+static hipError_t gemvN_sa(Ctx &c, int m, int n, double alpha, const double *a, int lda, const double *x, int incx,
+                           double beta, double *y, int incy, int round_mode, hipStream_t st)
+{
+    const int gx = (m + 63) / 64;
+    int KS = (c.num_cu * 4 + gx - 1) / gx;
+    const int max_ks = (n + 255) / 256;
+    if (KS > max_ks) KS = max_ks;
+    if (KS < 1) KS = 1;
+    const int kper = (n + KS - 1) / KS;
+    KS = (n + kper - 1) / kper;
+    const size_t ws_bytes = (size_t)m * SET_WORDS * sizeof(long long);
+    long long *ws = (long long *)workspace(c, ws_bytes);
+    hipError_t e = hipMemsetAsync(ws, 0, ws_bytes, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_gemvN_sa, dim3(gx, KS), dim3(GV_BLOCK), 0, st, m, n, alpha, a, (long long)lda, x,
+                       (long long)incx, kper, ws);
+    hipLaunchKernelGGL(k_gemv_finish, dim3((m + GV_WAVES - 1) / GV_WAVES), dim3(GV_BLOCK), 0, st, m, 0,
+                       (const double *)nullptr, ws, beta, y, (long long)incy, round_mode);
+    return hipGetLastError();
+}
+
+template <int N, bool EE>
+static hipError_t gemvT(Ctx &c, int m, int n, double alpha, const double *a, int lda, const double *x, int incx,
+                        double beta, double *y, int incy, int round_mode, hipStream_t st)
+{
+    (void)c;
+    constexpr int COPIES = (N == 0) ? 16 : 8;
+    hipLaunchKernelGGL((k_gemvT<N, EE, COPIES>), dim3(n), dim3(GV_BLOCK), 0, st, m, alpha, a, (long long)lda, x,
+                       (long long)incx, beta, y, (long long)incy, round_mode);
+    return hipGetLastError();
+}
+
+template <int N, bool EE>
+static hipError_t gemv_variant(Ctx &c, bool trans, int m, int n, double alpha, const double *a, int lda,
+                               const double *x, int incx, double beta, double *y, int incy, int round_mode,
+                               hipStream_t st)
+{
+    if (trans) return gemvT<N, EE>(c, m, n, alpha, a, lda, x, incx, beta, y, incy, round_mode, st);
+    if constexpr (N == 0) return gemvN_sa(c, m, n, alpha, a, lda, x, incx, beta, y, incy, round_mode, st);
+    else return gemvN_fpe<N, EE>(c, m, n, alpha, a, lda, x, incx, beta, y, incy, round_mode, st);
+}
+
+// variant selection: ExGEMV.cpp:81-107 (fpe == 0 superaccumulators, fpe == 1 plain DGEMV, early-exit buckets 4/6/8)
+hipError_t exgemv_dispatch(Ctx &c, char transa, int m, int n, double alpha, const double *a, int lda, const double *x,
+                           int incx, double beta, double *y, int incy, int fpe, int early_exit, int round_mode,
+                           hipStream_t st)
+{
+    if (m <= 0 || n <= 0) return hipSuccess;
+    const bool t = (transa == 'T' || transa == 't');
+#define GV_ARGS c, t, m, n, alpha, a, lda, x, incx, beta, y, incy, round_mode, st
+    if (fpe == 0) return gemv_variant<0, false>(GV_ARGS);
+    if (fpe == 1) {
+        if (t)
+            hipLaunchKernelGGL(k_dgemvT, dim3(n), dim3(64), 0, st, m, alpha, a, (long long)lda, x, (long long)incx, beta,
+                               y, (long long)incy);
+        else
+            hipLaunchKernelGGL(k_dgemvN, dim3((m + GV_BLOCK - 1) / GV_BLOCK), dim3(GV_BLOCK), 0, st, m, n, alpha, a,
+                               (long long)lda, x, (long long)incx, beta, y, (long long)incy);
+        return hipGetLastError();
+    }
+    if (early_exit) {
+        if (fpe <= 4) return gemv_variant<4, true>(GV_ARGS);
+        if (fpe <= 6) return gemv_variant<6, true>(GV_ARGS);
+        if (fpe <= 8) return gemv_variant<8, true>(GV_ARGS);
+        return hipSuccess;
+    }
+    switch (fpe) {
+    case 2: return gemv_variant<2, false>(GV_ARGS);
+    case 3: return gemv_variant<3, false>(GV_ARGS);
+    case 4: return gemv_variant<4, false>(GV_ARGS);
+    case 5: return gemv_variant<5, false>(GV_ARGS);
+    case 6: return gemv_variant<6, false>(GV_ARGS);
+    case 7: return gemv_variant<7, false>(GV_ARGS);
+    case 8: return gemv_variant<8, false>(GV_ARGS);
+    default: return hipSuccess;  // unsupported size: y untouched, like the reference's silent return
+    }
+#undef GV_ARGS
+}
+
 }  // namespace exb

@@ -1,0 +1,130 @@
+// fpe.hip.h -- register-resident floating-point expansions (FPE) shared by the blas1/2/3 kernels.
+//
+// Behavioural counterpart of the reference's expansion code (src/cpu/blas/blas1/ExSUM.FPE.hpp:316-417
+// FPExpansionVect::Accumulate/Flush; src/gpu/blas/blas1/ExSUM.FPE.cl:230-388 and ExDOT.FPE.cl:226-270 for
+// the per-work-item GPU form).  One expansion = N doubles per lane, most significant first; an element is
+// pushed down the cascade with Knuth TwoSum and whatever is left after N levels goes to a "sink": an
+// integer superaccumulator in LDS (blas1, gemvT, gemm) or a per-row one in global memory (gemv).
+#pragma once
+#include "superacc.hip.h"
+
+namespace exb {
+
+typedef double d2_t __attribute__((ext_vector_type(2)));
+
+template <bool NT>
+__device__ __forceinline__ d2_t ld2(const d2_t *p)
+{
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+
+// biased exponent field of a double, and the guard threshold 2^1000 (see fpe_absorb_sink)
+__device__ __forceinline__ unsigned expo_field(double x) { return ((unsigned)__double2hiint(x) >> 20) & 0x7ffu; }
+constexpr unsigned BIG_EXPO = 1023u + 1000u;
+
+// ---- sinks -----------------------------------------------------------------------------------
+template <int COPIES>
+struct LdsSink {
+    long long *col;   // this lane's column of the wave's LDS accumulator, stride COPIES between limbs
+    unsigned &flags;
+    __device__ __forceinline__ void add(double x) { lds_add<COPIES>(col, x, flags); }
+};
+
+// limbs of one accumulator in global memory: acc[0..NL) + three non-finite indicators at NL..NL+2
+struct GlobalSink {
+    long long *acc;
+    __device__ __forceinline__ void add(double x)
+    {
+        const unsigned long long u = (unsigned long long)__double_as_longlong(x);
+        unsigned be = (unsigned)(u >> 52) & 0x7ffu;
+        unsigned long long m = u & 0x000fffffffffffffull;
+        if (be == 0x7ffu) {
+            atomicAdd((unsigned long long *)&acc[NL + (m ? 2 : ((u >> 63) ? 1 : 0))], 1ull);
+            return;
+        }
+        if (be) m |= 0x0010000000000000ull; else be = 1u;
+        const unsigned p = be - 1u;
+        const unsigned idx = p >> 5, sh = p & 31u;
+        const unsigned long long lo = m << sh;
+        const unsigned hi = (unsigned)((m >> 32) >> (32u - sh));
+        long long c0 = (long long)(lo & 0xffffffffull), c1 = (long long)(lo >> 32), c2 = (long long)hi;
+        if (u >> 63) { c0 = -c0; c1 = -c1; c2 = -c2; }
+        unsigned long long *q = (unsigned long long *)(acc + idx);
+        if (c0) atomicAdd(q, (unsigned long long)c0);
+        if (c1) atomicAdd(q + 1, (unsigned long long)c1);
+        if (c2) atomicAdd(q + 2, (unsigned long long)c2);
+    }
+};
+
+// ---- the cascade -----------------------------------------------------------------------------
+// Push CNT elements (a "tile") through expansion levels from..N-1.  EE: one wave-uniform test per
+// level per tile ends the cascade as soon as every residue of every lane is zero.
+template <int N, bool EE, int CNT, class Sink>
+__device__ __forceinline__ void fpe_absorb_sink(double (&a)[N > 0 ? N : 1], double (&x)[CNT], int from, Sink &sink)
+{
+    if constexpr (N == 0) {
+#pragma unroll
+        for (int j = 0; j < CNT; ++j) sink.add(x[j]);
+    } else {
+        if (from == 0) {
+            // Range guard (one wave-uniform test per tile): TwoSum is only error-free while a + x stays
+            // finite.  Elements of magnitude >= 2^1000 and Inf/NaN bypass the expansion and go straight to
+            // the integer accumulator (which holds them exactly, resp. classifies them), and a[0] is spilled
+            // once it reaches 2^1000 -- so a[0] never exceeds (1 + CNT) * 2^1000 and cannot overflow.  The
+            // reference has no such guard (ExSUM.FPE.hpp:408 "TODO ... Inf/Overflow/NaN").
+            unsigned mx = expo_field(a[0]);
+#pragma unroll
+            for (int j = 0; j < CNT; ++j) mx = max(mx, expo_field(x[j]));
+            if (__any(mx >= BIG_EXPO)) {
+#pragma unroll
+                for (int j = 0; j < CNT; ++j)
+                    if (expo_field(x[j]) >= BIG_EXPO) {
+                        sink.add(x[j]);
+                        x[j] = 0.0;
+                    }
+                if (expo_field(a[0]) >= BIG_EXPO) {
+                    sink.add(a[0]);
+                    a[0] = 0.0;
+                }
+            }
+        }
+        bool live = true;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            if (i >= from && live) {
+#pragma unroll
+                for (int j = 0; j < CNT; ++j) {
+                    double s;
+                    a[i] = two_sum(a[i], x[j], s);
+                    x[j] = s;
+                }
+                if (EE && i > from) {
+                    bool nz = false;
+#pragma unroll
+                    for (int j = 0; j < CNT; ++j) nz |= (x[j] != 0.0);
+                    live = __any(nz);  // wave-uniform
+                }
+            }
+        }
+        if (live) {
+#pragma unroll
+            for (int j = 0; j < CNT; ++j)
+                if (x[j] != 0.0) sink.add(x[j]);
+        }
+    }
+}
+
+template <int N, class Sink>
+__device__ __forceinline__ void fpe_flush_sink(double (&a)[N > 0 ? N : 1], Sink &sink)
+{
+    if constexpr (N > 0) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            if (a[i] != 0.0) sink.add(a[i]);
+            a[i] = 0.0;
+        }
+    }
+}
+
+}  // namespace exb

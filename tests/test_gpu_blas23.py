@@ -1,0 +1,101 @@
+"""GPU parity tests for ExGEMV / ExGEMM against the oracle (bit-exact) and MPFR."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GEMV_VARIANTS = [(0, False), (2, False), (3, False), (4, False), (8, False), (4, True), (6, True), (8, True)]
+GEMM_VARIANTS = [(0, False), (3, False), (4, False), (8, False), (4, True), (6, True), (8, True)]
+
+
+@pytest.fixture(scope="module")
+def ex():
+    import torch
+    import exblas_amd
+    assert torch.cuda.is_available()
+    exblas_amd.load_library().exblas_hip_init(-1)
+    return exblas_amd
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.int64)
+
+
+@pytest.mark.parametrize("trans", ["N", "T"])
+@pytest.mark.parametrize("m,n", [(256, 256), (384, 200), (130, 517), (1, 9), (7, 1), (1030, 770)])
+def test_exgemv_vs_oracle(ex, oracle, trans, m, n):
+    """the reference's CTest matrix: trans N/T x (m=n, m<n, m>n), column-major, alpha=beta=1 (blas2/CMakeLists.txt:11-64)"""
+    for kind, p0, p1 in (("fpuniform", 10, 0), ("fpuniform_signed", 60, 30), ("lognormal", 0.0, 2.0)):
+        lda = m + (3 if (m % 2) else 2)
+        a = oracle.gen(kind, lda * n, 51, p0, p1)
+        rows, inner = (n, m) if trans == "T" else (m, n)
+        x = oracle.gen(kind, inner, 52, p0, p1)
+        y0 = oracle.gen(kind, rows, 53, p0, p1)
+        want = oracle.exgemv(trans, m, n, 1.0, a, lda, x, 1.0, y0, 0)
+        if oracle.mpfr() is not None and m * n < 100000:
+            a_dense = a.reshape(n, lda)[:, :m].copy().reshape(-1)
+            assert (_bits(oracle.mpfr_exgemv(trans, m, n, 1.0, a_dense, m, x, 1.0, y0)) == _bits(want)).all()
+        for fpe, ee in GEMV_VARIANTS:
+            y = y0.copy()
+            ex.exgemv(trans, m, n, 1.0, a, lda, 0, x, 1, 0, 1.0, y, 1, 0, fpe, ee)
+            assert (_bits(y) == _bits(want)).all(), (trans, m, n, kind, fpe, ee, np.nonzero(y != want)[0][:5])
+
+
+def test_exgemv_alpha_beta_strides_offsets(ex, oracle):
+    m, n, lda = 300, 210, 301
+    a = oracle.gen("fpuniform_signed", lda * n + 5, 61, 40, 20)
+    for trans in ("N", "T"):
+        rows, inner = (n, m) if trans == "T" else (m, n)
+        x = oracle.gen("fpuniform_signed", 2 * inner + 3, 62, 40, 20)
+        y0 = oracle.gen("fpuniform_signed", 3 * rows + 2, 63, 40, 20)
+        for alpha, beta in ((1.0, 0.0), (2.5, 1.0), (-0.3, 0.7)):
+            want = oracle.exgemv(trans, m, n, alpha, a, lda, x, beta, y0, 0, incx=2, incy=3, offa=5, offx=3, offy=2)
+            for fpe, ee in ((0, False), (4, False), (8, True)):
+                y = y0.copy()
+                ex.exgemv(trans, m, n, alpha, a, lda, 5, x, 2, 3, beta, y, 3, 2, fpe, ee)
+                assert (_bits(y) == _bits(want)).all(), (trans, alpha, beta, fpe, ee)
+
+
+def test_dgemv_baseline_close(ex, oracle):
+    m, n = 200, 300
+    a = oracle.gen("fpuniform", m * n, 71, 10, 0)
+    x = oracle.gen("fpuniform", max(m, n), 72, 10, 0)
+    for trans in ("N", "T"):
+        rows, inner = (n, m) if trans == "T" else (m, n)
+        y = np.ones(rows)
+        ex.exgemv(trans, m, n, 1.0, a, m, 0, x[:inner], 1, 0, 1.0, y, 1, 0, 1)   # fpe == 1: plain DGEMV
+        want = oracle.exgemv(trans, m, n, 1.0, a, m, x[:inner], 1.0, np.ones(rows), 0)
+        assert np.max(np.abs(y - want) / np.abs(want)) < 1e-13   # tolerance 1e-13: not reproducible by design
+
+
+@pytest.mark.parametrize("m,n,k", [(256, 256, 256), (33, 47, 129), (16, 16, 5), (100, 20, 300)])
+def test_exgemm_vs_oracle(ex, oracle, m, n, k):
+    """reference CTest: 256^3 row-major alpha=beta=1 (blas3/CMakeLists.txt:11-18); plus ragged shapes"""
+    for kind, p0, p1 in (("fpuniform", 10, 0), ("fpuniform_signed", 40, 20)):
+        a = oracle.gen(kind, m * k, 81, p0, p1)
+        b = oracle.gen(kind, k * n, 82, p0, p1)
+        c0 = oracle.gen(kind, m * n, 83, p0, p1)
+        want = oracle.exgemm("N", "N", m, n, k, 1.0, a, k, b, n, 1.0, c0, n, 0)
+        if oracle.mpfr() is not None and m * n * k < 3000000:
+            dots = oracle.mpfr_exgemm_dots(m, n, k, a, k, b, n).reshape(-1)
+            assert (_bits(c0 + dots) == _bits(want)).all()
+        variants = GEMM_VARIANTS if m * n * k <= 256 ** 3 // 4 else [(0, False), (4, False), (8, True)]
+        for fpe, ee in variants:
+            c = c0.copy()
+            ex.exgemm("N", "N", m, n, k, 1.0, a, k, b, n, 1.0, c, n, fpe, ee)
+            assert (_bits(c) == _bits(want)).all(), (m, n, k, kind, fpe, ee)
+
+
+def test_exgemm_trans_alpha_beta(ex, oracle):
+    m, n, k = 40, 56, 72
+    for ta, tb in (("N", "T"), ("T", "N"), ("T", "T")):
+        lda = (m if ta == "T" else k) + 1
+        ldb = (k if tb == "T" else n) + 2
+        a = oracle.gen("fpuniform_signed", (k if ta == "T" else m) * lda, 91, 30, 10)
+        b = oracle.gen("fpuniform_signed", (n if tb == "T" else k) * ldb, 92, 30, 10)
+        c0 = oracle.gen("fpuniform_signed", m * (n + 3), 93, 30, 10)
+        for alpha, beta in ((1.0, 1.0), (0.5, 0.0), (-1.25, 2.0)):
+            want = oracle.exgemm(ta, tb, m, n, k, alpha, a, lda, b, ldb, beta, c0, n + 3, 4, False)
+            c = c0.copy()
+            ex.exgemm(ta, tb, m, n, k, alpha, a, lda, b, ldb, beta, c, n + 3, 4, False)
+            assert (_bits(c) == _bits(want)).all(), (ta, tb, alpha, beta)
