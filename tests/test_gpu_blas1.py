@@ -152,3 +152,15 @@ def test_full_size_properties(ex, oracle):
     r1, l1 = oracle.exdot_omp(host, hy, 8, True, 16, limbs=True)
     assert (d.canon == l1).all() and same_double(d.exact, r1)
     torch.cuda.synchronize()
+
+
+def test_standalone_cpp_caller(ex):
+    """The reference-style C++ test program, linked only against libexblas.so (no Python in the process)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "cpp", "test_exsum_gpu")
+    subprocess.run(["make", "-C", os.path.join(root, "tests", "cpp")], check=True, capture_output=True)
+    for argv in (["20"], ["20", "50", "0"], ["20", "1e32", "0", "i"], ["18", "2", "0", "n"]):
+        r = subprocess.run([exe, *argv], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "TestPassed; ALL OK!" in r.stdout, (argv, r.stdout[-2000:], r.stderr[-2000:])
