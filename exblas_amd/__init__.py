@@ -29,6 +29,7 @@ C_ABI_SYMBOLS = [
     "exblas_exgemm_dev", "exblas_gen_dev", "exblas_stream_read_dev", "exblas_exsum", "exblas_exdot",
     "exblas_exgemv", "exblas_exgemm", "exblas_exsum_record", "exblas_exdot_record",
     "exblas_exsum_accumulate_dev", "exblas_exdot_accumulate_dev", "exblas_finish_dev", "exblas_set_tuning",
+    "exblas_set_gemm_path", "exblas_last_gemm_slices",
 ]
 
 _lib = None
@@ -62,6 +63,8 @@ def load_library():
     L.exblas_hip_version.restype = C.c_char_p
     L.exblas_set_round_mode.argtypes = [i32]
     L.exblas_set_tuning.argtypes = [i32, i32, i32]
+    L.exblas_set_gemm_path.argtypes = [i32]
+    L.exblas_set_gemm_path.restype = None
     L.exblas_exsum_dev.argtypes = [vp, i64, i64, i32, i32, vp, vp]
     L.exblas_exdot_dev.argtypes = [vp, i64, vp, i64, i64, i32, i32, vp, vp]
     L.exblas_finalize_dev.argtypes = [vp, i32, C.c_uint32, vp, vp]

@@ -115,8 +115,17 @@ hipError_t exgemm_dispatch(Ctx &c, char transa, char transb, int m, int n, int k
                            int lda, const double *b, int ldb, double beta, double *cmat, int ldc, int fpe,
                            int early_exit, int round_mode, hipStream_t st)
 {
-    (void)c;
     if (m <= 0 || n <= 0) return hipSuccess;
+    c.last_gemm_slices = 0;
+    // MFMA-F64 fast path (blas3_mfma.hip): exact-rounding mode only; mode 0 = for the expansion variants when the
+    // data qualifies, 1 = never, 2 = for every variant.  Falls through to the scalar kernel otherwise.
+    if (round_mode == 0 && c.gemm_path != 1 && (fpe >= 3 || c.gemm_path == 2)) {
+        const bool variant_ok = !early_exit ? (fpe <= 8) : true;
+        if (variant_ok) {
+            hipError_t e = hipSuccess;
+            if (exgemm_try_mfma(c, transa, transb, m, n, k, alpha, a, lda, b, ldb, beta, cmat, ldc, st, &e)) return e;
+        }
+    }
 #define GM_ARGS transa, transb, m, n, k, alpha, a, lda, b, ldb, beta, cmat, ldc, round_mode, st
     if (fpe < 3) return gemm_variant<0, false>(GM_ARGS);
     if (early_exit) {

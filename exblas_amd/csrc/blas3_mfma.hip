@@ -1,0 +1,413 @@
+// blas3_mfma.hip -- ExGEMM fast path: error-free slicing + v_mfma_f64_16x16x4_f64, exact by construction.
+//
+// The north star asks for MFMA_F64 in the panel x panel contraction "that feeds the accumulator".  An MFMA
+// rounds every fused multiply-add, so it can only be used where no rounding can happen.  We make that so
+// with an Ozaki-style error-free split (Ozaki, Ogita, Oishi, Rump, "Error-free transformations of matrix
+// multiplication", Numer. Algorithms 59, 2012), done with integer shifts instead of floating-point tricks:
+//
+//   * row i of A' = fl(alpha*A) has a scale ea_i (|A'_il| < 2^ea_i), column j of B a scale eb_j;
+//   * every entry is cut into S slices of BETA = 21 bits: A'_il = sign * sum_p a_p(i,l) * 2^(ea_i - BETA*p),
+//     0 <= a_p < 2^21 (p = 1..SA), likewise b_q(l,j) -- a scan kernel measures how many slices the data needs
+//     (mantissa bits actually used + exponent spread inside the row/column) and the host picks SA, SB <= 4,
+//     or falls back to the scalar kernel (k_gemm) when the spread is wider;
+//   * for a k-block of KP = 512 the integer products a_p*b_q (< 2^42) are contracted on the matrix cores in
+//     fp64; all pairs with the same d = p+q share one accumulator:  KP * min(SA,SB) * 2^42 <= 2^53, so every
+//     MFMA partial sum is an integer below 2^53 and therefore exact, in any summation order;
+//   * after each k-block the (SA+SB-1) accumulators per output are converted to int64 and added, shifted by
+//     BETA*(SA+SB-d), into a 256-bit two's-complement fixed-point accumulator held in registers -- the Kulisch
+//     accumulator of this output, shrunk to the window the scales allow (no LDS, no global spill);
+//   * the epilogue rounds that integer once (round-to-nearest-even) and scales it by 2^(ea_i+eb_j-BETA*(SA+SB)).
+//
+// Result: bit-identical to k_gemm / the oracle / MPFR (tests/test_gpu_blas23.py), with the O(mnk) work on
+// the MFMA pipe.  On gfx950 the f64 MFMA rate equals the f64 VALU FMA rate (78.6 TFLOP/s), so the gain over
+// k_gemm is the ~30 VALU ops per product of the TwoProd+TwoSum chain against SA*SB MFMA-FMAs per product.
+#include "superacc.hip.h"
+#include "exblas_internal.h"
+
+#include <type_traits>
+
+namespace exb {
+
+typedef double v4d_t __attribute__((ext_vector_type(4)));
+
+// compile-time loop: f(std::integral_constant<int, I>) for I in [B, E)
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+
+constexpr int MF_BETA = 21;
+constexpr int MF_KP = 512;    // k-block over which MFMA partial sums stay exact
+constexpr int MF_BN = 64, MF_KB = 16;  // BM = 32 * RT (RT = 16-row MFMA tiles per wave: 2, or 1 for S = 4 to stay in registers)
+constexpr int MF_LDP = 80;    // padded leading dimension of the [k][row] slice planes
+constexpr int MF_THREADS = 256;
+
+// info words written by the scan kernels
+enum { INFO_NEED_A = 0, INFO_NEED_B = 1, INFO_FLAGS = 2, INFO_EMIN = 3, INFO_EMAX = 4, INFO_WORDS = 8 };
+
+// ---------------------------------------------------------------------------------------------
+// scan: per vector (row of A' / column of B) the scale, and globally the number of bits to cover
+// ---------------------------------------------------------------------------------------------
+struct ScanAcc {
+    int emax, lsbmin;
+    unsigned bad;
+    __device__ __forceinline__ void init() { emax = -100000; lsbmin = 100000; bad = 0; }
+    __device__ __forceinline__ void add(double x)
+    {
+        const unsigned long long u = (unsigned long long)__double_as_longlong(x);
+        const unsigned be = (unsigned)(u >> 52) & 0x7ffu;
+        const unsigned long long frac = u & 0x000fffffffffffffull;
+        if (be == 0) {
+            if (frac) bad = 1;  // subnormal input: scalar path
+            return;             // zero
+        }
+        if (be == 0x7ffu) { bad = 1; return; }
+        const int e = (int)be - 1023;
+        const unsigned long long mant = frac | 0x0010000000000000ull;
+        const int lsb = e - 52 + __builtin_ctzll(mant);
+        emax = max(emax, e);
+        lsbmin = min(lsbmin, lsb);
+    }
+    __device__ __forceinline__ void merge(const ScanAcc &o)
+    {
+        emax = max(emax, o.emax);
+        lsbmin = min(lsbmin, o.lsbmin);
+        bad |= o.bad;
+    }
+};
+
+__device__ __forceinline__ void scan_publish(const ScanAcc &s, int *scale_out, int *info, int need_slot)
+{
+    const bool empty = s.emax < -50000;
+    *scale_out = empty ? 0 : s.emax + 1;
+    if (!empty) {
+        atomicMax(&info[need_slot], s.emax + 1 - s.lsbmin);
+        atomicMin(&info[INFO_EMIN], s.emax);
+        atomicMax(&info[INFO_EMAX], s.emax);
+    }
+    if (s.bad) atomicOr((unsigned *)&info[INFO_FLAGS], 1u);
+}
+
+// vectors whose elements are contiguous (stride 1 along the reduction): one workgroup per vector
+__global__ void __launch_bounds__(256) k_scan_contig(const double *__restrict__ p, long long ldv, int nvec, int len,
+                                                     double scale, int *scale_out, int *info, int need_slot)
+{
+    __shared__ ScanAcc red[256];
+    const int v = blockIdx.x;
+    if (v >= nvec) return;
+    ScanAcc s;
+    s.init();
+    const double *q = p + (long long)v * ldv;
+    for (int i = threadIdx.x; i < len; i += 256) s.add(scale * q[i]);
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x].merge(red[threadIdx.x + o]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) scan_publish(red[0], &scale_out[v], info, need_slot);
+}
+
+// vectors whose elements are strided by ldv (adjacent vectors are contiguous): one thread per vector
+__global__ void __launch_bounds__(256) k_scan_strided(const double *__restrict__ p, long long ldv, int nvec, int len,
+                                                      double scale, int *scale_out, int *info, int need_slot)
+{
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= nvec) return;
+    ScanAcc s;
+    s.init();
+    for (int i = 0; i < len; ++i) s.add(scale * p[(long long)i * ldv + v]);
+    scan_publish(s, &scale_out[v], info, need_slot);
+}
+
+// ---------------------------------------------------------------------------------------------
+// slicing: |x| / 2^(ea - BETA*S) as an integer (exact by the scan's guarantee), cut into S chunks of BETA bits
+// ---------------------------------------------------------------------------------------------
+template <int S>
+__device__ __forceinline__ void slice(double x, int ea, double (&out)[S])
+{
+    const unsigned long long u = (unsigned long long)__double_as_longlong(x);
+    const unsigned be = (unsigned)(u >> 52) & 0x7ffu;
+    if (be == 0) {
+#pragma unroll
+        for (int p = 0; p < S; ++p) out[p] = 0.0;
+        return;
+    }
+    const unsigned long long mant = (u & 0x000fffffffffffffull) | 0x0010000000000000ull;
+    const int e = (int)be - 1023;
+    // X = mant * 2^t, t = (e - 52) - (ea - BETA*S); X < 2^(BETA*S) <= 2^84
+    const int t = e - 52 - ea + MF_BETA * S;
+    unsigned __int128 X = (unsigned __int128)mant;
+    if (t >= 0) X <<= t; else X >>= (-t);  // right shifts drop only zero bits (scan: need <= BETA*S)
+    const double sgn = (u >> 63) ? -1.0 : 1.0;
+#pragma unroll
+    for (int p = 0; p < S; ++p) {
+        const unsigned chunk = (unsigned)(X >> (MF_BETA * (S - 1 - p))) & ((1u << MF_BETA) - 1u);
+        out[p] = sgn * (double)chunk;  // exact small integer
+    }
+}
+
+// 256-bit accumulator += sign_extend(T) << SH   (SH is a compile-time constant after unrolling)
+template <int SH>
+__device__ __forceinline__ void wide_add(unsigned long long (&acc)[4], long long T)
+{
+    constexpr int w = SH >> 6, b = SH & 63;
+    const unsigned long long ext = (unsigned long long)(T >> 63);
+    const unsigned long long lo = (unsigned long long)T << b;
+    const unsigned long long hi = b ? (unsigned long long)(T >> (64 - b)) : ext;
+    unsigned long long v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (i < w) ? 0ull : (i == w ? lo : (i == w + 1 ? hi : ext));
+    unsigned long long c = 0, cn;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        acc[i] = __builtin_addcll(acc[i], v[i], c, &cn);
+        c = cn;
+    }
+}
+
+// round the 256-bit two's-complement integer to nearest-even and scale by 2^unit_exp (result stays normal:
+// the host only takes this path when all scales are within +-400)
+__device__ inline double wide_round(const unsigned long long (&in)[4], int unit_exp)
+{
+    unsigned long long m[4] = {in[0], in[1], in[2], in[3]};
+    const bool neg = (long long)m[3] < 0;
+    if (neg) {
+        unsigned long long c = 1, cn;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            m[i] = __builtin_addcll(~m[i], 0ull, c, &cn);
+            c = cn;
+        }
+    }
+    int top = 3;
+    while (top > 0 && m[top] == 0) --top;
+    if (m[top] == 0) return 0.0;
+    const int lz = __builtin_clzll(m[top]);
+    const int msb = 64 * top + 63 - lz;
+    double r;
+    if (msb <= 52) {
+        r = ldexp((double)m[0], unit_exp);
+    } else {
+        const unsigned long long below = top > 0 ? m[top - 1] : 0ull;
+        unsigned long long w = lz ? ((m[top] << lz) | (below >> (64 - lz))) : m[top];
+        bool sticky = (w & 0x3ffull) != 0 || (lz ? (below << lz) != 0 : below != 0);
+        for (int i = top - 2; i >= 0; --i) sticky |= m[i] != 0;
+        unsigned long long mant = w >> 11;
+        if (((w >> 10) & 1ull) && (sticky || (mant & 1ull))) mant += 1;  // may reach 2^53: still exact in fp64
+        r = ldexp((double)mant, msb - 52 + unit_exp);
+    }
+    return neg ? -r : r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// the kernel: 64x64 outputs per workgroup, each wave a 32x32 quadrant = 2x2 MFMA tiles of 16x16
+// ---------------------------------------------------------------------------------------------
+template <int SA, int SB, int RT>
+__global__ void __launch_bounds__(MF_THREADS, 1) k_gemm_mfma(int ta, int tb, int m, int n, int k, double alpha,
+                                                             const double *__restrict__ a, long long lda,
+                                                             const double *__restrict__ b, long long ldb, double beta,
+                                                             double *__restrict__ c, long long ldc,
+                                                             const int *__restrict__ EA, const int *__restrict__ EB)
+{
+    constexpr int G = SA + SB - 1;  // accumulator groups d = p+q, d-2 in [0, G)
+    constexpr int D = SA + SB;
+    __shared__ double As[SA][MF_KB][MF_LDP];  // [slice][k][row (BM <= 64) + pad]
+    __shared__ double Bs[SB][MF_KB][MF_LDP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int BM = 32 * RT;
+    constexpr int AEPT = BM * MF_KB / MF_THREADS;  // A elements per thread per k-step (4 or 2)
+    const int i0 = blockIdx.y * BM, j0 = blockIdx.x * MF_BN;
+    const int wr = (wave >> 1) * (16 * RT), wc = (wave & 1) * 32;
+
+    // global -> register staging: 4 elements of A and 4 of B per thread per k-step
+    // A tile 64 rows x 16 k: thread -> (row = tid/4, kq = (tid%4)*4 .. +3); B tile 16 k x 64 cols: (kk = tid/16, cq = (tid%16)*4 .. +3)
+    const int ar = tid / (MF_KB / AEPT), akq = (tid % (MF_KB / AEPT)) * AEPT;
+    const int bk = tid >> 4, bcq = (tid & 15) * 4;
+    const int a_row = i0 + ar;
+    const int ea_r = (a_row < m) ? EA[a_row] : 0;
+    int eb_c[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) eb_c[u] = (j0 + bcq + u < n) ? EB[j0 + bcq + u] : 0;
+
+    auto load_a = [&](int l0, double (&ra)[AEPT]) {
+#pragma unroll
+        for (int u = 0; u < AEPT; ++u) {
+            const int gl = l0 + akq + u;
+            double v = 0.0;
+            if (a_row < m && gl < k) v = alpha * (ta ? a[(long long)gl * lda + a_row] : a[(long long)a_row * lda + gl]);
+            ra[u] = v;
+        }
+    };
+    auto load_b = [&](int l0, double (&rb)[4]) {
+        const int gl = l0 + bk;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int gj = j0 + bcq + u;
+            double v = 0.0;
+            if (gl < k && gj < n) v = tb ? b[(long long)gj * ldb + gl] : b[(long long)gl * ldb + gj];
+            rb[u] = v;
+        }
+    };
+
+    unsigned long long wide[RT][2][4][4];  // [row tile][col tile][reg][limb]
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int w = 0; w < 4; ++w) wide[rt][ct][r][w] = 0ull;
+
+    double ra[AEPT], rb[4];
+    load_a(0, ra);
+    load_b(0, rb);
+    for (int kb = 0; kb < k; kb += MF_KP) {
+        v4d_t acc[G][RT][2];
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) acc[g][rt][ct] = (v4d_t){0.0, 0.0, 0.0, 0.0};
+        const int kend = min(k, kb + MF_KP);
+        for (int l0 = kb; l0 < kend; l0 += MF_KB) {
+            __syncthreads();  // previous step's fragments consumed
+#pragma unroll
+            for (int u = 0; u < AEPT; ++u) {
+                double sa[SA];
+                slice<SA>(ra[u], ea_r, sa);
+#pragma unroll
+                for (int p = 0; p < SA; ++p) As[p][akq + u][ar] = sa[p];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                double sb[SB];
+                slice<SB>(rb[u], eb_c[u], sb);
+#pragma unroll
+                for (int q = 0; q < SB; ++q) Bs[q][bk][bcq + u] = sb[q];
+            }
+            // prefetch the next k-step while this one is contracted
+            const int ln = l0 + MF_KB;
+            if (ln < k) {
+                load_a(ln, ra);
+                load_b(ln, rb);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int kk = 0; kk < MF_KB; kk += 4) {
+                double fa[RT][SA], fb[2][SB];
+                const int kx = kk + (lane >> 4);
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int p = 0; p < SA; ++p) fa[rt][p] = As[p][kx][wr + rt * 16 + (lane & 15)];
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int q = 0; q < SB; ++q) fb[ct][q] = Bs[q][kx][wc + ct * 16 + (lane & 15)];
+#pragma unroll
+                for (int p = 0; p < SA; ++p)
+#pragma unroll
+                    for (int q = 0; q < SB; ++q)
+#pragma unroll
+                        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                            for (int ct = 0; ct < 2; ++ct)
+                                acc[p + q][rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[rt][p], fb[ct][q],
+                                                                                          acc[p + q][rt][ct], 0, 0, 0);
+            }
+        }
+        // fold the exact group sums of this k-block into the wide integers: group g holds pairs with
+        // p+q = g+2 (1-based), i.e. weight 2^(-BETA*(g+2)); unit of the wide integer = 2^(-BETA*D)
+        static_for<0, G>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        wide_add<MF_BETA * (D - (g + 2))>(wide[rt][ct][r], __double2ll_rn(acc[g][rt][ct][r]));
+        });
+    }
+    // epilogue: f64 MFMA C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gi = i0 + wr + rt * 16 + (lane >> 4) + 4 * r;
+                const int gj = j0 + wc + ct * 16 + (lane & 15);
+                if (gi < m && gj < n) {
+                    const double s = wide_round(wide[rt][ct][r], EA[gi] + EB[gj] - MF_BETA * D);
+                    double *cij = c + (long long)gi * ldc + gj;
+                    *cij = (beta == 0.0) ? s : beta * (*cij) + s;
+                }
+            }
+}
+
+template <int SA, int SB, int RT>
+static void launch_mfma(int ta, int tb, int m, int n, int k, double alpha, const double *a, int lda, const double *b,
+                        int ldb, double beta, double *c, int ldc, const int *EA, const int *EB, hipStream_t st)
+{
+    constexpr int BM = 32 * RT;
+    dim3 grid((n + MF_BN - 1) / MF_BN, (m + BM - 1) / BM);
+    hipLaunchKernelGGL((k_gemm_mfma<SA, SB, RT>), grid, dim3(MF_THREADS), 0, st, ta, tb, m, n, k, alpha, a, (long long)lda,
+                       b, (long long)ldb, beta, c, (long long)ldc, EA, EB);
+}
+
+// Returns true when the MFMA path ran; false -> caller uses the scalar kernel.  Synchronises the stream once
+// (the slice counts are read back on the host).
+bool exgemm_try_mfma(Ctx &c, char transa, char transb, int m, int n, int k, double alpha, const double *a, int lda,
+                     const double *b, int ldb, double beta, double *cmat, int ldc, hipStream_t st, hipError_t *err)
+{
+    *err = hipSuccess;
+    c.last_gemm_slices = 0;
+    if (k <= 0) return false;
+    const int ta = (transa == 'T' || transa == 't'), tb = (transb == 'T' || transb == 't');
+    int *buf = (int *)workspace(c, sizeof(int) * ((size_t)m + n + INFO_WORDS));
+    int *info = buf, *EA = buf + INFO_WORDS, *EB = EA + m;
+    const int init[INFO_WORDS] = {0, 0, 0, 100000, -100000, 0, 0, 0};
+    if ((*err = hipMemcpyAsync(info, init, sizeof(init), hipMemcpyHostToDevice, st)) != hipSuccess) return true;
+    // rows of A' (reduction over l)
+    if (!ta)
+        hipLaunchKernelGGL(k_scan_contig, dim3(m), dim3(256), 0, st, a, (long long)lda, m, k, alpha, EA, info, INFO_NEED_A);
+    else
+        hipLaunchKernelGGL(k_scan_strided, dim3((m + 255) / 256), dim3(256), 0, st, a, (long long)lda, m, k, alpha, EA, info,
+                           INFO_NEED_A);
+    // columns of B (reduction over l)
+    if (!tb)
+        hipLaunchKernelGGL(k_scan_strided, dim3((n + 255) / 256), dim3(256), 0, st, b, (long long)ldb, n, k, 1.0, EB, info,
+                           INFO_NEED_B);
+    else
+        hipLaunchKernelGGL(k_scan_contig, dim3(n), dim3(256), 0, st, b, (long long)ldb, n, k, 1.0, EB, info, INFO_NEED_B);
+    int h[INFO_WORDS];
+    if ((*err = hipMemcpyAsync(h, info, sizeof(h), hipMemcpyDeviceToHost, st)) != hipSuccess) return true;
+    if ((*err = hipStreamSynchronize(st)) != hipSuccess) return true;
+    if (h[INFO_FLAGS]) return false;                        // Inf/NaN/subnormal input
+    if (h[INFO_EMAX] < h[INFO_EMIN]) return false;          // all-zero operand: let the scalar kernel handle it
+    if (h[INFO_EMIN] < -400 || h[INFO_EMAX] > 400) return false;  // keep every result in the normal range
+    const int sa = (h[INFO_NEED_A] + MF_BETA - 1) / MF_BETA, sb = (h[INFO_NEED_B] + MF_BETA - 1) / MF_BETA;
+    const int s = sa > sb ? sa : sb;
+    if (s > 4 || s < 1) return false;
+    // k-blocks: (k / KP) * G * 2^53 must fit the 256-bit accumulator: 53 + BETA*(2S-2) + log2(k/KP * G) < 255
+#define MF_GO(S, RT) launch_mfma<S, S, RT>(ta, tb, m, n, k, alpha, a, lda, b, ldb, beta, cmat, ldc, EA, EB, st)
+    switch (s) {
+    case 1: case 2: MF_GO(2, 2); break;
+    case 3: MF_GO(3, 2); break;
+    default: MF_GO(4, 1); break;
+    }
+#undef MF_GO
+    c.last_gemm_slices = s < 2 ? 2 : s;
+    *err = hipGetLastError();
+    return true;
+}
+
+}  // namespace exb

@@ -79,6 +79,7 @@ Ctx &ctx(int device)
         c.ngroups = env_int("EXBLAS_NGROUPS", 32);
         if (c.ngroups < 1) c.ngroups = 1;
         c.variant = env_int("EXBLAS_VARIANT", 0);
+        c.gemm_path = env_int("EXBLAS_GEMM_PATH", 0);
         EXB_CHECK(hipMalloc(&c.gacc, sizeof(long long) * NL * c.ngroups));
         EXB_CHECK(hipMemset(c.gacc, 0, sizeof(long long) * NL * c.ngroups));
         EXB_CHECK(hipMalloc(&c.gflags, 64));
@@ -263,6 +264,15 @@ int exblas_set_tuning(int blocks_per_cu, int ngroups, int variant)
     return 0;
 }
 int exblas_get_round_mode(void) { return round_mode(); }
+
+int exblas_last_gemm_slices(void) { return ctx(-1).last_gemm_slices; }
+
+void exblas_set_gemm_path(int mode)
+{
+    Ctx &c = ctx(-1);
+    std::lock_guard<std::mutex> lk(c.mu);
+    c.gemm_path = mode;
+}
 
 int exblas_exsum_accumulate_dev(const double *d_a, int64_t n, int64_t inca, int fpe, int early_exit, void *stream)
 {

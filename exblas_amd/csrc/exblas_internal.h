@@ -18,6 +18,8 @@ struct Ctx {
     int bpc_sum = 2, bpc_dot = 16;
     int ngroups = 32;        // EXBLAS_NGROUPS: global group accumulators the blocks add into
     int variant = 0;         // tuning variant of the production kernels (exblas_set_tuning)
+    int last_gemm_slices = 0;  // 0: the last exgemm ran the scalar kernel; 2..4: MFMA path with that many slices
+    int gemm_path = 0;       // 0 auto (MFMA-F64 slices when the data qualifies), 1 scalar only, 2 MFMA for every fpe
     long long *gacc = nullptr;   // [ngroups][NL] int64, zero between calls
     unsigned *gflags = nullptr;  // non-finite input flags, zero between calls
     // host-pointer API staging
@@ -58,6 +60,9 @@ hipError_t exgemv_dispatch(Ctx &c, char transa, int m, int n, double alpha, cons
 hipError_t exgemm_dispatch(Ctx &c, char transa, char transb, int m, int n, int k, double alpha, const double *a,
                            int lda, const double *b, int ldb, double beta, double *cmat, int ldc, int fpe,
                            int early_exit, int round_mode, hipStream_t st);
+
+bool exgemm_try_mfma(Ctx &c, char transa, char transb, int m, int n, int k, double alpha, const double *a, int lda,
+                     const double *b, int ldb, double beta, double *cmat, int ldc, hipStream_t st, hipError_t *err);
 
 int round_mode();
 

@@ -58,6 +58,11 @@ const char *exblas_hip_version(void);
 /* Launch-geometry knobs for A/B measurements (<= 0 / < 0 leave a value unchanged): resident blocks per CU
  * of the streaming kernels, number of global group accumulators, kernel variant (0 = production). */
 int exblas_set_tuning(int blocks_per_cu, int ngroups, int variant);
+/* ExGEMM implementation: 0 = auto (error-free slices on MFMA-F64 for the expansion variants when the data
+ * qualifies, scalar kernel otherwise), 1 = scalar kernel only, 2 = MFMA path for every fpe.  Same bits either way. */
+void exblas_set_gemm_path(int mode);
+/* which implementation the last exgemm used: 0 = scalar kernel, 2..4 = MFMA path with that many slices */
+int exblas_last_gemm_slices(void);
 /* 0 = exact, 1 = reference; overrides EXBLAS_ROUND for the host-pointer API */
 void exblas_set_round_mode(int mode);
 int exblas_get_round_mode(void);

@@ -99,3 +99,47 @@ def test_exgemm_trans_alpha_beta(ex, oracle):
             c = c0.copy()
             ex.exgemm(ta, tb, m, n, k, alpha, a, lda, b, ldb, beta, c, n + 3, 4, False)
             assert (_bits(c) == _bits(want)).all(), (ta, tb, alpha, beta)
+
+
+@pytest.mark.parametrize("m,n,k", [(64, 64, 512), (130, 75, 1100), (16, 200, 33)])
+def test_exgemm_mfma_path_is_exact(ex, oracle, m, n, k):
+    """The MFMA-F64 slice path (blas3_mfma.hip) against the oracle and the scalar kernel, bit for bit."""
+    lib = ex.load_library()
+    rng = np.random.default_rng(5)
+    cases = {
+        "fpuniform_r10": (oracle.gen("fpuniform", m * k, 81, 10, 0), oracle.gen("fpuniform", k * n, 82, 10, 0), 3),
+        "signed_r20": (oracle.gen("fpuniform_signed", m * k, 83, 20, 10), oracle.gen("fpuniform_signed", k * n, 84, 20, 10), 4),
+        "naive": (oracle.gen("naive", m * k, 1), oracle.gen("naive", k * n, 1), 3),
+        "small_ints": (rng.integers(-1000, 1000, m * k).astype(np.float64), rng.integers(-1000, 1000, k * n).astype(np.float64), 2),
+        "wide_r60": (oracle.gen("fpuniform_signed", m * k, 85, 60, 30), oracle.gen("fpuniform_signed", k * n, 86, 60, 30), 0),
+    }
+    try:
+        for name, (a, b, want_slices) in cases.items():
+            c0 = oracle.gen("fpuniform_signed", m * n, 87, 10, 5)
+            want = oracle.exgemm("N", "N", m, n, k, 1.0, a, k, b, n, 1.0, c0, n, 0)
+            for path, fpe, ee in ((0, 8, True), (2, 0, False), (1, 8, True)):
+                lib.exblas_set_gemm_path(path)
+                c = c0.copy()
+                ex.exgemm("N", "N", m, n, k, 1.0, a, k, b, n, 1.0, c, n, fpe, ee)
+                used = lib.exblas_last_gemm_slices()
+                assert (_bits(c) == _bits(want)).all(), (name, path, fpe, used, int((c != want).sum()))
+                if path != 1:
+                    assert used == want_slices, (name, path, used, want_slices)
+                else:
+                    assert used == 0
+        # transposes / alpha / beta through the MFMA path
+        lib.exblas_set_gemm_path(2)
+        for ta, tb in (("N", "T"), ("T", "N"), ("T", "T")):
+            lda = (m if ta == "T" else k) + 1
+            ldb = (k if tb == "T" else n) + 2
+            a = oracle.gen("fpuniform_signed", (k if ta == "T" else m) * lda, 91, 8, 4)
+            b = oracle.gen("fpuniform_signed", (n if tb == "T" else k) * ldb, 92, 8, 4)
+            c0 = oracle.gen("fpuniform_signed", m * (n + 3), 93, 8, 4)
+            for alpha, beta in ((1.0, 1.0), (0.5, 0.0), (-1.25, 2.0)):
+                want = oracle.exgemm(ta, tb, m, n, k, alpha, a, lda, b, ldb, beta, c0, n + 3, 4, False)
+                c = c0.copy()
+                ex.exgemm(ta, tb, m, n, k, alpha, a, lda, b, ldb, beta, c, n + 3, 4, False)
+                assert lib.exblas_last_gemm_slices() >= 2
+                assert (_bits(c) == _bits(want)).all(), (ta, tb, alpha, beta)
+    finally:
+        lib.exblas_set_gemm_path(0)
