@@ -123,6 +123,40 @@ def cpu_baseline(op, host_arrays, fpe, ee, limbs_gpu):
     }, ok
 
 
+def bench_blas23(ex, torch, world, rank):
+    """ExGEMV m=n=32768 'N' column-major per GPU (config 4; replicas for N > 1) and ExGEMM n=8192 row-sharded
+    over the ranks (config 5: each rank owns 8192/N rows of A and C, B replicated, no collective)."""
+    def timeit(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    m = n = 32768
+    a = ex.gen_dev("fpuniform", m * n, 11, 10.0, 0.0)
+    x = ex.gen_dev("fpuniform", n, 12, 10.0, 0.0)
+    y = ex.gen_dev("fpuniform", m, 13, 10.0, 0.0)
+    ms = timeit(lambda: ex.exgemv_dev("N", m, n, 1.0, a, m, x, 1.0, y, 8, True), 10)
+    gv = {"workload": "ExGEMV 'N' m=n=32768 fp64 column-major alpha=beta=1, fpe=8 early_exit, per GPU", "ms": ms,
+          "bytes": 8.0 * (m * n + n + 2 * m)}
+    del a
+    N = 8192
+    r0, r1 = ex.row_block(N, rank, world)
+    A = ex.gen_dev("fpuniform", N * N, 14, 10.0, 0.0, first=r0 * N, count=(r1 - r0) * N)
+    B = ex.gen_dev("fpuniform", N * N, 15, 10.0, 0.0)
+    C = torch.zeros((r1 - r0) * N, dtype=torch.float64, device="cuda")
+    ms = timeit(lambda: ex.exgemm_rows(r1 - r0, N, N, 1.0, A, B, 0.0, C, 8, True), 2)
+    gm = {"workload": f"ExGEMM n=8192 fp64 row-major alpha=1, rows sharded over {world} GPU(s), "
+                      "MFMA-F64 slice path", "ms": ms, "flop_total": 2.0 * N * N * N,
+          "slices": ex.load_library().exblas_last_gemm_slices()}
+    return {"exgemv": gv, "exgemm": gm}
+
+
 def main():
     args = parse()
     import torch
@@ -193,6 +227,15 @@ def main():
                      "result": ex.read_record(rec2).exact}
         del y
 
+    # BASELINE configs 4 and 5 on the same box (kernel-chain time by HIP events; parity is covered by tests/)
+    blas23 = None
+    if not args.no_secondary and args.op == "exsum":
+        blas23 = bench_blas23(ex, torch, world, rank)
+        if world > 1:
+            t = torch.tensor([blas23["exgemv"]["ms"], blas23["exgemm"]["ms"]], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            blas23["exgemv"]["ms"], blas23["exgemm"]["ms"] = float(t[0]), float(t[1])
+
     out = None
     if rank == 0:
         achieved = n * bytes_per_elem / (kms * 1e-3) / 1e9
@@ -228,6 +271,13 @@ def main():
         }
         if secondary:
             out["exdot"] = secondary
+        if blas23:
+            gv, gm = blas23["exgemv"], blas23["exgemm"]
+            gv["GBs"] = gv["bytes"] * world / (gv["ms"] * 1e-3) / 1e9
+            gv["frac_hbm_peak"] = gv["bytes"] / (gv["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+            gm["TFLOPs_2mnk"] = gm["flop_total"] / (gm["ms"] * 1e-3) / 1e12
+            out["exgemv"] = gv
+            out["exgemm"] = gm
         if world == 1 and not args.no_cpu_baseline:
             host = [t.cpu().numpy() for t in tensors]
             base, ok = cpu_baseline(args.op, host, args.fpe, ee, result.canon)

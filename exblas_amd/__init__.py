@@ -309,4 +309,5 @@ def exgemm(transa, transb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, fpe, ea
                                         fpe, int(bool(early_exit)))
 
 
-from .dist import exsum_allreduce, exdot_allreduce, allreduce_record, shard_range  # noqa: E402,F401
+from .dist import (exsum_allreduce, exdot_allreduce, allreduce_record, shard_range, row_block,  # noqa: E402,F401
+                   exgemv_rows, exgemm_rows)

@@ -22,12 +22,12 @@ constexpr int BLOCK = 256;
 constexpr int WAVES = BLOCK / 64;
 
 // blas1 sinks everything into the wave's LDS accumulator column
-template <int N, bool EE, int COPIES, int CNT>
+template <int N, bool EE, int COPIES, int CNT, int ZM = 0>
 __device__ __forceinline__ void fpe_absorb(double (&a)[N > 0 ? N : 1], double (&x)[CNT], int from,
                                            long long *col, unsigned &flags)
 {
     LdsSink<COPIES> sink{col, flags};
-    fpe_absorb_sink<N, EE, CNT>(a, x, from, sink);
+    fpe_absorb_sink<N, EE, CNT, LdsSink<COPIES>, ZM>(a, x, from, sink);
 }
 
 template <int N, int COPIES>
@@ -62,7 +62,7 @@ __device__ __forceinline__ void block_epilogue(long long *s_acc, unsigned flags,
 // ---------------------------------------------------------------------------------------------
 // ExSUM, contiguous input
 // ---------------------------------------------------------------------------------------------
-template <int N, bool EE, int COPIES, int U, bool NT, bool PF>
+template <int N, bool EE, int COPIES, int U, bool NT, bool PF, int ZM = 0>
 __global__ void __launch_bounds__(BLOCK) k_exsum(const double *__restrict__ a, long long n,
                                                  long long *__restrict__ gacc,
                                                  unsigned *__restrict__ gflags, int ngroups)
@@ -96,7 +96,7 @@ __global__ void __launch_bounds__(BLOCK) k_exsum(const double *__restrict__ a, l
                 x[2 * u] = r[u].x;
                 x[2 * u + 1] = r[u].y;
             }
-            fpe_absorb<N, EE, COPIES, 2 * U>(fpe, x, 0, col, flags);
+            fpe_absorb<N, EE, COPIES, 2 * U, ZM>(fpe, x, 0, col, flags);
         }
     } else {
         // register double-buffering: the next tile's loads are in flight while this one is absorbed
@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(BLOCK) k_exsum(const double *__restrict__ a, l
 #pragma unroll
                 for (int u = 0; u < U; ++u) r[u] = ld2<NT>(p + u * BLOCK);
             }
-            fpe_absorb<N, EE, COPIES, 2 * U>(fpe, x, 0, col, flags);
+            fpe_absorb<N, EE, COPIES, 2 * U, ZM>(fpe, x, 0, col, flags);
             t = tn;
         }
     }
@@ -178,10 +178,10 @@ __global__ void __launch_bounds__(BLOCK) k_exdot(const double *__restrict__ a, c
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     long long *col = s_acc + wave * NL * COPIES + (lane & (COPIES - 1));
     unsigned flags = 0;
+    LdsSink<COPIES> sink{col, flags};
     double fpe[N > 0 ? N : 1];
 #pragma unroll
     for (int i = 0; i < (N > 0 ? N : 1); ++i) fpe[i] = 0.0;
-    constexpr int EFROM = (N >= 3) ? N - 3 : 0;
 
     // vector path only when both streams are 16-byte aligned (host guarantees or falls to strided)
     const d2_t *va = (const d2_t *)a, *vb = (const d2_t *)b;
@@ -200,11 +200,10 @@ __global__ void __launch_bounds__(BLOCK) k_exdot(const double *__restrict__ a, c
             double x[2 * U], e[2 * U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                x[2 * u] = two_prod_safe(ra[u].x, rb[u].x, e[2 * u]);
-                x[2 * u + 1] = two_prod_safe(ra[u].y, rb[u].y, e[2 * u + 1]);
+                x[2 * u] = two_prod(ra[u].x, rb[u].x, e[2 * u]);
+                x[2 * u + 1] = two_prod(ra[u].y, rb[u].y, e[2 * u + 1]);
             }
-            fpe_absorb<N, EE, COPIES, 2 * U>(fpe, x, 0, col, flags);
-            fpe_absorb<N, EE, COPIES, 2 * U>(fpe, e, EFROM, col, flags);
+            fpe_absorb_prod<N, EE, 2 * U>(fpe, x, e, sink);
         }
     } else {
         long long t = blockIdx.x;
@@ -221,8 +220,8 @@ __global__ void __launch_bounds__(BLOCK) k_exdot(const double *__restrict__ a, c
             double x[2 * U], e[2 * U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                x[2 * u] = two_prod_safe(ra[u].x, rb[u].x, e[2 * u]);
-                x[2 * u + 1] = two_prod_safe(ra[u].y, rb[u].y, e[2 * u + 1]);
+                x[2 * u] = two_prod(ra[u].x, rb[u].x, e[2 * u]);
+                x[2 * u + 1] = two_prod(ra[u].y, rb[u].y, e[2 * u + 1]);
             }
             const long long tn = t + gridDim.x;
             if (tn < ntiles) {
@@ -233,8 +232,7 @@ __global__ void __launch_bounds__(BLOCK) k_exdot(const double *__restrict__ a, c
                     rb[u] = ld2<NT>(vb + base + u * BLOCK);
                 }
             }
-            fpe_absorb<N, EE, COPIES, 2 * U>(fpe, x, 0, col, flags);
-            fpe_absorb<N, EE, COPIES, 2 * U>(fpe, e, EFROM, col, flags);
+            fpe_absorb_prod<N, EE, 2 * U>(fpe, x, e, sink);
             t = tn;
         }
     }
@@ -242,10 +240,9 @@ __global__ void __launch_bounds__(BLOCK) k_exdot(const double *__restrict__ a, c
          i += (long long)gridDim.x * BLOCK) {
         d2_t ra = va[i], rb = vb[i];
         double x[2], e[2];
-        x[0] = two_prod_safe(ra.x, rb.x, e[0]);
-        x[1] = two_prod_safe(ra.y, rb.y, e[1]);
-        fpe_absorb<N, false, COPIES, 2>(fpe, x, 0, col, flags);
-        fpe_absorb<N, false, COPIES, 2>(fpe, e, EFROM, col, flags);
+        x[0] = two_prod(ra.x, rb.x, e[0]);
+        x[1] = two_prod(ra.y, rb.y, e[1]);
+        fpe_absorb_prod<N, false, 2>(fpe, x, e, sink);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0 && (n & 1)) {
         double e, p = two_prod_safe(a[n - 1], b[n - 1], e);
@@ -268,15 +265,14 @@ __global__ void __launch_bounds__(BLOCK) k_exdot_strided(const double *__restric
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     long long *col = s_acc + wave * NL * COPIES + (lane & (COPIES - 1));
     unsigned flags = 0;
+    LdsSink<COPIES> sink{col, flags};
     double fpe[N > 0 ? N : 1];
 #pragma unroll
     for (int i = 0; i < (N > 0 ? N : 1); ++i) fpe[i] = 0.0;
-    constexpr int EFROM = (N >= 3) ? N - 3 : 0;
     for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (long long)gridDim.x * BLOCK) {
         double x[1], e[1];
-        x[0] = two_prod_safe(a[i * inca], b[i * incb], e[0]);
-        fpe_absorb<N, false, COPIES, 1>(fpe, x, 0, col, flags);
-        fpe_absorb<N, false, COPIES, 1>(fpe, e, EFROM, col, flags);
+        x[0] = two_prod(a[i * inca], b[i * incb], e[0]);
+        fpe_absorb_prod<N, false, 1>(fpe, x, e, sink);
     }
     fpe_flush<N, COPIES>(fpe, col, flags);
     block_epilogue<COPIES>(s_acc, flags, gacc, gflags, ngroups);
@@ -337,11 +333,11 @@ static inline int grid_for(const Ctx &c, long long work_items, long long per_blo
     return (int)(want < cap ? want : cap);
 }
 
-template <int N, bool EE, int COPIES, int U, bool NT, bool PF>
+template <int N, bool EE, int COPIES, int U, bool NT, bool PF, int ZM = 0>
 static void run_exsum(Ctx &c, const double *a, long long n, hipStream_t st)
 {
     int grid = grid_for(c, n, (long long)BLOCK * 2 * U, c.bpc_sum);
-    hipLaunchKernelGGL((k_exsum<N, EE, COPIES, U, NT, PF>), dim3(grid), dim3(BLOCK), 0, st, a, n, c.gacc, c.gflags,
+    hipLaunchKernelGGL((k_exsum<N, EE, COPIES, U, NT, PF, ZM>), dim3(grid), dim3(BLOCK), 0, st, a, n, c.gacc, c.gflags,
                        c.ngroups);
 }
 
@@ -360,6 +356,7 @@ static hipError_t launch_exsum(Ctx &c, const double *a, long long n, long long i
             case 5: run_exsum<N, EE, COPIES, 2, true, false>(c, a, n, st); break;
             case 6: run_exsum<N, EE, COPIES, 8, true, true>(c, a, n, st); break;
             case 7: run_exsum<N, EE, COPIES, 6, true, true>(c, a, n, st); break;
+            case 8: run_exsum<N, EE, COPIES, 4, true, true, 1>(c, a, n, st); break;
             default: run_exsum<N, EE, COPIES, 4, true, true>(c, a, n, st); break;
             }
         } else {

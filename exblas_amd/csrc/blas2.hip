@@ -36,7 +36,6 @@ __global__ void __launch_bounds__(GV_BLOCK) k_gemvN_fpe(int m, int n, double alp
     const int ks = blockIdx.y, KS = gridDim.y;
     const int k0 = ks * kper, k1 = min(n, k0 + kper);
     const bool v0 = r0 < m, v1 = r0 + 1 < m;
-    constexpr int EFROM = (N >= 3) ? N - 3 : 0;
     double f0[N], f1[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) f0[i] = f1[i] = 0.0;
@@ -66,23 +65,19 @@ __global__ void __launch_bounds__(GV_BLOCK) k_gemvN_fpe(int m, int n, double alp
                 }
                 double p[U], e[U];
 #pragma unroll
-                for (int j = 0; j < U; ++j) p[j] = two_prod_safe(ax[j], xs[k + j], e[j]);
-                fpe_absorb_sink<N, EE, U>(f0, p, 0, s0);
-                fpe_absorb_sink<N, EE, U>(f0, e, EFROM, s0);
+                for (int j = 0; j < U; ++j) p[j] = two_prod(ax[j], xs[k + j], e[j]);
+                fpe_absorb_prod<N, EE, U>(f0, p, e, s0);
 #pragma unroll
-                for (int j = 0; j < U; ++j) p[j] = two_prod_safe(ay[j], xs[k + j], e[j]);
-                fpe_absorb_sink<N, EE, U>(f1, p, 0, s1);
-                fpe_absorb_sink<N, EE, U>(f1, e, EFROM, s1);
+                for (int j = 0; j < U; ++j) p[j] = two_prod(ay[j], xs[k + j], e[j]);
+                fpe_absorb_prod<N, EE, U>(f1, p, e, s1);
             }
             for (; k < cnt; ++k) {
                 const double ax = col[lda * k], ay = v1 ? col[lda * k + 1] : 0.0;
                 double p[1], e[1];
-                p[0] = two_prod_safe(ax, xs[k], e[0]);
-                fpe_absorb_sink<N, false, 1>(f0, p, 0, s0);
-                fpe_absorb_sink<N, false, 1>(f0, e, EFROM, s0);
-                p[0] = two_prod_safe(ay, xs[k], e[0]);
-                fpe_absorb_sink<N, false, 1>(f1, p, 0, s1);
-                fpe_absorb_sink<N, false, 1>(f1, e, EFROM, s1);
+                p[0] = two_prod(ax, xs[k], e[0]);
+                fpe_absorb_prod<N, false, 1>(f0, p, e, s0);
+                p[0] = two_prod(ay, xs[k], e[0]);
+                fpe_absorb_prod<N, false, 1>(f1, p, e, s1);
             }
         }
     }
@@ -211,7 +206,6 @@ __global__ void __launch_bounds__(GV_BLOCK) k_gemvT(int m, double alpha, const d
     const double *col = a + lda * j;
     unsigned flags = 0;
     LdsSink<COPIES> sink{s_acc + wave * NL * COPIES + (lane & (COPIES - 1)), flags};
-    constexpr int EFROM = (N >= 3) ? N - 3 : 0;
     double f[N > 0 ? N : 1];
 #pragma unroll
     for (int i = 0; i < (N > 0 ? N : 1); ++i) f[i] = 0.0;
@@ -233,19 +227,17 @@ __global__ void __launch_bounds__(GV_BLOCK) k_gemvT(int m, double alpha, const d
             double p[2 * U], e[2 * U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                p[2 * u] = two_prod_safe(ra[u].x, alpha * rx[u].x, e[2 * u]);
-                p[2 * u + 1] = two_prod_safe(ra[u].y, alpha * rx[u].y, e[2 * u + 1]);
+                p[2 * u] = two_prod(ra[u].x, alpha * rx[u].x, e[2 * u]);
+                p[2 * u + 1] = two_prod(ra[u].y, alpha * rx[u].y, e[2 * u + 1]);
             }
-            fpe_absorb_sink<N, EE, 2 * U>(f, p, 0, sink);
-            fpe_absorb_sink<N, EE, 2 * U>(f, e, EFROM, sink);
+            fpe_absorb_prod<N, EE, 2 * U>(f, p, e, sink);
         }
         done = ntiles * tile * 2;
     }
     for (long long i = done + tid; i < m; i += GV_BLOCK) {
         double p[1], e[1];
-        p[0] = two_prod_safe(col[i], alpha * x[i * incx], e[0]);
-        fpe_absorb_sink<N, false, 1>(f, p, 0, sink);
-        fpe_absorb_sink<N, false, 1>(f, e, EFROM, sink);
+        p[0] = two_prod(col[i], alpha * x[i * incx], e[0]);
+        fpe_absorb_prod<N, false, 1>(f, p, e, sink);
     }
     fpe_flush_sink<N>(f, sink);
     if (tid == 0 && beta != 0.0) {

@@ -34,7 +34,6 @@ __global__ void __launch_bounds__(GM_THREADS) k_gemm(int ta, int tb, int m, int 
     for (int t = tid; t < NL * GM_THREADS; t += GM_THREADS) acc[t] = 0;
     unsigned flags = 0;
     LdsSink<GM_THREADS> sink{acc + tid, flags};
-    constexpr int EFROM = (N >= 3) ? N - 3 : 0;
     double f[N > 0 ? N : 1];
 #pragma unroll
     for (int q = 0; q < (N > 0 ? N : 1); ++q) f[q] = 0.0;
@@ -61,17 +60,8 @@ __global__ void __launch_bounds__(GM_THREADS) k_gemm(int ta, int tb, int m, int 
         for (int l = 0; l < GM_KB; l += 4) {
             double p[4], e[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) p[u] = two_prod_safe(As[ty][l + u], Bs[l + u][tx], e[u]);
-            if constexpr (N == 0) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    sink.add(p[u]);
-                    if (e[u] != 0.0) sink.add(e[u]);
-                }
-            } else {
-                fpe_absorb_sink<N, EE, 4>(f, p, 0, sink);
-                fpe_absorb_sink<N, EE, 4>(f, e, EFROM, sink);
-            }
+            for (int u = 0; u < 4; ++u) p[u] = two_prod(As[ty][l + u], Bs[l + u][tx], e[u]);
+            fpe_absorb_prod<N, EE, 4>(f, p, e, sink);
         }
     }
     fpe_flush_sink<N>(f, sink);

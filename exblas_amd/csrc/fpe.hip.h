@@ -23,6 +23,25 @@ __device__ __forceinline__ d2_t ld2(const d2_t *p)
 __device__ __forceinline__ unsigned expo_field(double x) { return ((unsigned)__double2hiint(x) >> 20) & 0x7ffu; }
 constexpr unsigned BIG_EXPO = 1023u + 1000u;
 
+// "is any of these doubles non-zero" with 32-bit integer ops only (two per element instead of an fp64
+// compare each): OR of the low words and the high words shifted left by one (drops the sign, so -0.0 is zero)
+template <int CNT, int ZM = 0>
+__device__ __forceinline__ bool any_nonzero(const double (&x)[CNT])
+{
+    if constexpr (ZM == 0) {
+        unsigned bits = 0;
+#pragma unroll
+        for (int j = 0; j < CNT; ++j)
+            bits |= ((unsigned)__double2hiint(x[j]) << 1) | (unsigned)__double2loint(x[j]);
+        return bits != 0;
+    } else {  // fp64 compares (A/B variant)
+        bool nz = false;
+#pragma unroll
+        for (int j = 0; j < CNT; ++j) nz |= (x[j] != 0.0);
+        return nz;
+    }
+}
+
 // ---- sinks -----------------------------------------------------------------------------------
 template <int COPIES>
 struct LdsSink {
@@ -58,60 +77,90 @@ struct GlobalSink {
 };
 
 // ---- the cascade -----------------------------------------------------------------------------
+// Range guard (one wave-uniform test per tile): TwoSum is only error-free while a + x stays finite.
+// Elements of magnitude >= 2^1000 and Inf/NaN bypass the expansion and go straight to the integer
+// accumulator (which holds them exactly, resp. classifies them), and a[0] is spilled once it reaches
+// 2^1000 -- so a[0] never exceeds (1 + CNT) * 2^1000 and cannot overflow.  The reference has no such
+// guard (ExSUM.FPE.hpp:408 "TODO ... Inf/Overflow/NaN").  `e` (optional): the TwoProd error terms that
+// belong to x; the error term of a non-finite product is meaningless (fma(a,b,-inf)) and is zeroed here.
+template <int CNT, class Sink>
+__device__ __forceinline__ void fpe_guard(double &a0, double (&x)[CNT], double *e, Sink &sink)
+{
+    unsigned mx = expo_field(a0);
+#pragma unroll
+    for (int j = 0; j < CNT; ++j) mx = max(mx, expo_field(x[j]));
+    if (__any(mx >= BIG_EXPO)) {
+#pragma unroll
+        for (int j = 0; j < CNT; ++j) {
+            const unsigned ex = expo_field(x[j]);
+            if (ex >= BIG_EXPO) {
+                sink.add(x[j]);
+                x[j] = 0.0;
+                if (e && ex == 0x7ffu) e[j] = 0.0;
+            }
+        }
+        if (expo_field(a0) >= BIG_EXPO) {
+            sink.add(a0);
+            a0 = 0.0;
+        }
+    }
+}
+
 // Push CNT elements (a "tile") through expansion levels from..N-1.  EE: one wave-uniform test per
 // level per tile ends the cascade as soon as every residue of every lane is zero.
-template <int N, bool EE, int CNT, class Sink>
+template <int N, bool EE, int CNT, class Sink, int ZM = 0>
+__device__ __forceinline__ void fpe_cascade(double (&a)[N > 0 ? N : 1], double (&x)[CNT], int from, Sink &sink)
+{
+    bool live = true;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        if (i >= from && live) {
+#pragma unroll
+            for (int j = 0; j < CNT; ++j) {
+                double s;
+                a[i] = two_sum(a[i], x[j], s);
+                x[j] = s;
+            }
+            if (EE && i > from) live = __any(any_nonzero<CNT, ZM>(x));  // wave-uniform
+        }
+    }
+    // what survived every level goes to the integer accumulator (rare: one wave-uniform test first)
+    if (live && __any(any_nonzero<CNT, ZM>(x))) {
+#pragma unroll
+        for (int j = 0; j < CNT; ++j)
+            if (x[j] != 0.0) sink.add(x[j]);
+    }
+}
+
+template <int N, bool EE, int CNT, class Sink, int ZM = 0>
 __device__ __forceinline__ void fpe_absorb_sink(double (&a)[N > 0 ? N : 1], double (&x)[CNT], int from, Sink &sink)
 {
     if constexpr (N == 0) {
 #pragma unroll
         for (int j = 0; j < CNT; ++j) sink.add(x[j]);
     } else {
-        if (from == 0) {
-            // Range guard (one wave-uniform test per tile): TwoSum is only error-free while a + x stays
-            // finite.  Elements of magnitude >= 2^1000 and Inf/NaN bypass the expansion and go straight to
-            // the integer accumulator (which holds them exactly, resp. classifies them), and a[0] is spilled
-            // once it reaches 2^1000 -- so a[0] never exceeds (1 + CNT) * 2^1000 and cannot overflow.  The
-            // reference has no such guard (ExSUM.FPE.hpp:408 "TODO ... Inf/Overflow/NaN").
-            unsigned mx = expo_field(a[0]);
+        if (from == 0) fpe_guard<CNT>(a[0], x, nullptr, sink);
+        fpe_cascade<N, EE, CNT, Sink, ZM>(a, x, from, sink);
+    }
+}
+
+// Products: p[j] + e[j] = a_j * b_j exactly (two_prod, NOT the _safe form: the guard handles overflow).
+// The rounding errors enter the expansion at slot max(N-3, 0) like ExDOT.FPE.cl:254.
+template <int N, bool EE, int CNT, class Sink>
+__device__ __forceinline__ void fpe_absorb_prod(double (&a)[N > 0 ? N : 1], double (&p)[CNT], double (&e)[CNT],
+                                                Sink &sink)
+{
+    if constexpr (N == 0) {
 #pragma unroll
-            for (int j = 0; j < CNT; ++j) mx = max(mx, expo_field(x[j]));
-            if (__any(mx >= BIG_EXPO)) {
-#pragma unroll
-                for (int j = 0; j < CNT; ++j)
-                    if (expo_field(x[j]) >= BIG_EXPO) {
-                        sink.add(x[j]);
-                        x[j] = 0.0;
-                    }
-                if (expo_field(a[0]) >= BIG_EXPO) {
-                    sink.add(a[0]);
-                    a[0] = 0.0;
-                }
-            }
+        for (int j = 0; j < CNT; ++j) {
+            sink.add(p[j]);
+            if (e[j] != 0.0 && expo_field(p[j]) != 0x7ffu) sink.add(e[j]);
         }
-        bool live = true;
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
-            if (i >= from && live) {
-#pragma unroll
-                for (int j = 0; j < CNT; ++j) {
-                    double s;
-                    a[i] = two_sum(a[i], x[j], s);
-                    x[j] = s;
-                }
-                if (EE && i > from) {
-                    bool nz = false;
-#pragma unroll
-                    for (int j = 0; j < CNT; ++j) nz |= (x[j] != 0.0);
-                    live = __any(nz);  // wave-uniform
-                }
-            }
-        }
-        if (live) {
-#pragma unroll
-            for (int j = 0; j < CNT; ++j)
-                if (x[j] != 0.0) sink.add(x[j]);
-        }
+    } else {
+        constexpr int EFROM = (N >= 3) ? N - 3 : 0;
+        fpe_guard<CNT>(a[0], p, e, sink);
+        fpe_cascade<N, EE, CNT>(a, p, 0, sink);
+        fpe_cascade<N, EE, CNT>(a, e, EFROM, sink);
     }
 }
 

@@ -48,3 +48,26 @@ def exdot_allreduce(x_local, y_local, fpe=8, early_exit=True, group=None, out=No
     from . import exdot_dev
     rec = exdot_dev(x_local, y_local, fpe=fpe, early_exit=early_exit, out=out)
     return _finish(rec, group)
+
+
+# ---------------------------------------------------------------------------------------------
+# ExGEMV / ExGEMM: outputs are independent, so the path shards by ROWS with no data-path collective
+# (SURVEY 8e): every rank owns a contiguous block of rows of A (and y resp. C) and the whole of x resp. B.
+# ---------------------------------------------------------------------------------------------
+def row_block(m, rank, world):
+    """[first, last) rows of this rank; even boundaries keep the 16-byte alignment of column-major A blocks."""
+    return shard_range(m, rank, world)
+
+
+def exgemv_rows(trans, m_local, n, alpha, a_local, lda_local, x, beta, y_local, fpe=8, early_exit=True):
+    """y_local := alpha*op(A_local)*x + beta*y_local for this rank's row block ('N': rows of A; column-major
+    A_local with leading dimension lda_local).  For trans == 'T' the reduction runs over the sharded dimension,
+    so callers shard the OUTPUT instead (columns of A) -- also independent, also no collective."""
+    from . import exgemv_dev
+    return exgemv_dev(trans, m_local, n, alpha, a_local, lda_local, x, beta, y_local, fpe, early_exit)
+
+
+def exgemm_rows(m_local, n, k, alpha, a_local, b, beta, c_local, fpe=8, early_exit=True):
+    """C_local := alpha*A_local*B + beta*C_local (row-major) for this rank's rows of A and C; B is replicated."""
+    from . import exgemm_dev
+    return exgemm_dev("N", "N", m_local, n, k, alpha, a_local, k, b, n, beta, c_local, n, fpe, early_exit)
