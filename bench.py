@@ -123,6 +123,14 @@ def cpu_baseline(op, host_arrays, fpe, ee, limbs_gpu):
     }, ok
 
 
+def load_traffic(path, kernel):
+    """Per-launch HBM bytes of `kernel` from the separate rocprofv3 --pmc passes (profiles/hbm_traffic.json)."""
+    try:
+        return json.load(open(path)).get(kernel)
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def bench_blas23(ex, torch, world, rank):
     """ExGEMV m=n=32768 'N' column-major per GPU (config 4; replicas for N > 1) and ExGEMM n=8192 row-sharded
     over the ranks (config 5: each rank owns 8192/N rows of A and C, B replicated, no collective)."""
@@ -222,7 +230,8 @@ def main():
         secondary = {"metric": "ExDOT fp64 Gelem/s", "value": n_total * args.steps / ddt / 1e9, "unit": "Gelem/s",
                      "ms_per_step": ddt / args.steps * 1e3,
                      "roofline": {"bound": "hbm", "achieved": dach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                  "frac": dach / HBM_PEAK_GBS, "traffic": None, "kernel": "k_exdot",
+                                  "frac": dach / HBM_PEAK_GBS, "traffic": load_traffic(args.traffic_json, "k_exdot"),
+                                  "kernel": "k_exdot",
                                   "kernel_ms": dkms},
                      "result": ex.read_record(rec2).exact}
         del y
@@ -239,12 +248,7 @@ def main():
     out = None
     if rank == 0:
         achieved = n * bytes_per_elem / (kms * 1e-3) / 1e9
-        traffic = None
-        if os.path.exists(args.traffic_json):
-            try:
-                traffic = json.load(open(args.traffic_json)).get(f"k_{args.op}")
-            except Exception:  # noqa: BLE001
-                traffic = None
+        traffic = load_traffic(args.traffic_json, f"k_{args.op}")
         out = {
             "metric": f"Ex{args.op[2:].upper()} fp64 Gelem/s at n=2^{args.log2n} per GPU (bit-exact vs CPU superaccumulator/MPFR)",
             "value": n_total * args.steps / dt / 1e9,
