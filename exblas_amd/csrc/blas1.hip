@@ -65,7 +65,7 @@ __device__ __forceinline__ void block_epilogue(long long *s_acc, unsigned flags,
 template <int N, bool EE, int COPIES, int U, bool NT, bool PF, int ZM = 0>
 __global__ void __launch_bounds__(BLOCK) k_exsum(const double *__restrict__ a, long long n,
                                                  long long *__restrict__ gacc,
-                                                 unsigned *__restrict__ gflags, int ngroups)
+                                                 unsigned *__restrict__ gflags, int ngroups, int chunked)
 {
     __shared__ long long s_acc[WAVES * NL * COPIES];
     for (int i = threadIdx.x; i < WAVES * NL * COPIES; i += BLOCK) s_acc[i] = 0;
@@ -99,23 +99,31 @@ __global__ void __launch_bounds__(BLOCK) k_exsum(const double *__restrict__ a, l
             fpe_absorb<N, EE, COPIES, 2 * U, ZM>(fpe, x, 0, col, flags);
         }
     } else {
-        // register double-buffering: the next tile's loads are in flight while this one is absorbed
-        long long t = blockIdx.x;
+        // register double-buffering: the next tile's loads are in flight while this one is absorbed.
+        // Tile -> workgroup map: strided (tile t to workgroup t mod grid: the grid sweeps one compact window
+        // of addresses) or chunked (each workgroup streams its own contiguous range).
+        long long t = blockIdx.x, tstride = gridDim.x, tend = ntiles;
+        if (chunked) {
+            const long long per = (ntiles + gridDim.x - 1) / gridDim.x;
+            t = blockIdx.x * per;
+            tstride = 1;
+            tend = min(ntiles, t + per);
+        }
         d2_t r[U];
-        if (t < ntiles) {
+        if (t < tend) {
             const d2_t *p = v + t * TILE + threadIdx.x;
 #pragma unroll
             for (int u = 0; u < U; ++u) r[u] = ld2<NT>(p + u * BLOCK);
         }
-        while (t < ntiles) {
+        while (t < tend) {
             double x[2 * U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 x[2 * u] = r[u].x;
                 x[2 * u + 1] = r[u].y;
             }
-            const long long tn = t + gridDim.x;
-            if (tn < ntiles) {
+            const long long tn = t + tstride;
+            if (tn < tend) {
                 const d2_t *p = v + tn * TILE + threadIdx.x;
 #pragma unroll
                 for (int u = 0; u < U; ++u) r[u] = ld2<NT>(p + u * BLOCK);
@@ -338,7 +346,7 @@ static void run_exsum(Ctx &c, const double *a, long long n, hipStream_t st)
 {
     int grid = grid_for(c, n, (long long)BLOCK * 2 * U, c.bpc_sum);
     hipLaunchKernelGGL((k_exsum<N, EE, COPIES, U, NT, PF, ZM>), dim3(grid), dim3(BLOCK), 0, st, a, n, c.gacc, c.gflags,
-                       c.ngroups);
+                       c.ngroups, c.variant == 9 ? 1 : 0);
 }
 
 template <int N, bool EE>

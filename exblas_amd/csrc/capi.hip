@@ -397,6 +397,7 @@ int exblas_exsum_record(int Ng, const double *ag, int inca, int offset, int fpe,
 {
     check_fpe(fpe);
     Ctx &c = ctx(-1);
+    std::lock_guard<std::mutex> api_lock(c.api_mu);
     const double *d_a = nullptr;
     {
         std::lock_guard<std::mutex> lk(c.mu);
@@ -424,6 +425,7 @@ int exblas_exdot_record(int Ng, const double *ag, int inca, int offseta, const d
 {
     check_fpe(fpe);
     Ctx &c = ctx(-1);
+    std::lock_guard<std::mutex> api_lock(c.api_mu);
     const double *d_a = nullptr, *d_b = nullptr;
     {
         std::lock_guard<std::mutex> lk(c.mu);
@@ -477,6 +479,7 @@ int exblas_exgemv(char transa, int m, int n, double alpha, const double *a, int 
     check_fpe(fpe);
     if (m <= 0 || n <= 0) return 0;
     Ctx &c = ctx(-1);
+    std::lock_guard<std::mutex> api_lock(c.api_mu);
     const bool trans = (transa == 'T' || transa == 't');
     const int rows = trans ? n : m, inner = trans ? m : n;
     double *d_a, *d_x, *d_y;
@@ -505,6 +508,7 @@ int exblas_exgemm(char transa, char transb, int m, int n, int k, double alpha, c
     check_fpe(fpe);
     if (m <= 0 || n <= 0) return 0;
     Ctx &c = ctx(-1);
+    std::lock_guard<std::mutex> api_lock(c.api_mu);
     const bool ta = (transa == 'T' || transa == 't'), tb = (transb == 'T' || transb == 't');
     // row-major storage (ExGEMM.Superacc.cl:254-255): A is m x k (k x m when transposed), etc.
     size_t abytes = (size_t)(ta ? k : m) * (size_t)lda * sizeof(double);

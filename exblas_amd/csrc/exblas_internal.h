@@ -31,7 +31,8 @@ struct Ctx {
     // blas2/blas3 workspaces
     void *ws = nullptr;
     size_t ws_bytes = 0;
-    std::mutex mu;
+    std::mutex mu;      // guards launches that touch the context workspace
+    std::mutex api_mu;  // held by a host-pointer call for its whole duration (staging buffers, record, stream)
 };
 
 Ctx &ctx(int device);

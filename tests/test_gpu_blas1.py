@@ -164,3 +164,13 @@ def test_standalone_cpp_caller(ex):
     for argv in (["20"], ["20", "50", "0"], ["20", "1e32", "0", "i"], ["18", "2", "0", "n"]):
         r = subprocess.run([exe, *argv], capture_output=True, text=True, timeout=300)
         assert r.returncode == 0 and "TestPassed; ALL OK!" in r.stdout, (argv, r.stdout[-2000:], r.stderr[-2000:])
+
+
+def test_concurrent_cpp_callers(ex):
+    """pthread-style concurrent use of the host-pointer API (the reference's RNGExample pattern)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["make", "-C", os.path.join(root, "tests", "cpp")], check=True, capture_output=True)
+    r = subprocess.run([os.path.join(root, "tests", "cpp", "test_threads")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "TestPassed; ALL OK!" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
