@@ -42,7 +42,7 @@ __device__ __forceinline__ void static_for(F &&f)
 
 constexpr int MF_BETA = 21;
 constexpr int MF_KP = 512;    // k-block over which MFMA partial sums stay exact
-constexpr int MF_BN = 64, MF_KB = 16;  // BM = 32 * RT (RT = 16-row MFMA tiles per wave: 2, or 1 for S = 4 to stay in registers)
+constexpr int MF_KB = 16;  // workgroup tile: BM = 32*RT rows x BN = 32*CT columns (RT x CT MFMA tiles of 16x16 per wave)
 constexpr int MF_LDP = 80;    // padded leading dimension of the [k][row] slice planes
 constexpr int MF_THREADS = 256;
 
@@ -80,21 +80,20 @@ struct ScanAcc {
     }
 };
 
-__device__ __forceinline__ void scan_publish(const ScanAcc &s, int *scale_out, int *info, int need_slot)
+// Both scan kernels only fold their part of a vector into vmax[v] / vlsb[v] (atomicMax / atomicMin), so the
+// reduction dimension can be split over workgroups; k_scan_finish then derives the scale and the global needs.
+__device__ __forceinline__ void scan_publish(const ScanAcc &s, int *vmax, int *vlsb, int *info)
 {
-    const bool empty = s.emax < -50000;
-    *scale_out = empty ? 0 : s.emax + 1;
-    if (!empty) {
-        atomicMax(&info[need_slot], s.emax + 1 - s.lsbmin);
-        atomicMin(&info[INFO_EMIN], s.emax);
-        atomicMax(&info[INFO_EMAX], s.emax);
+    if (s.emax > -50000) {
+        atomicMax(vmax, s.emax);
+        atomicMin(vlsb, s.lsbmin);
     }
     if (s.bad) atomicOr((unsigned *)&info[INFO_FLAGS], 1u);
 }
 
 // vectors whose elements are contiguous (stride 1 along the reduction): one workgroup per vector
 __global__ void __launch_bounds__(256) k_scan_contig(const double *__restrict__ p, long long ldv, int nvec, int len,
-                                                     double scale, int *scale_out, int *info, int need_slot)
+                                                     double scale, int *vmax, int *vlsb, int *info)
 {
     __shared__ ScanAcc red[256];
     const int v = blockIdx.x;
@@ -109,19 +108,47 @@ __global__ void __launch_bounds__(256) k_scan_contig(const double *__restrict__ 
         if ((int)threadIdx.x < o) red[threadIdx.x].merge(red[threadIdx.x + o]);
         __syncthreads();
     }
-    if (threadIdx.x == 0) scan_publish(red[0], &scale_out[v], info, need_slot);
+    if (threadIdx.x == 0) scan_publish(red[0], &vmax[v], &vlsb[v], info);
 }
 
-// vectors whose elements are strided by ldv (adjacent vectors are contiguous): one thread per vector
+// vectors whose elements are strided by ldv (adjacent vectors are contiguous): one thread per vector and
+// per slice of the reduction dimension (blockIdx.y)
 __global__ void __launch_bounds__(256) k_scan_strided(const double *__restrict__ p, long long ldv, int nvec, int len,
-                                                      double scale, int *scale_out, int *info, int need_slot)
+                                                      double scale, int *vmax, int *vlsb, int *info)
 {
     const int v = blockIdx.x * 256 + threadIdx.x;
     if (v >= nvec) return;
+    const int per = (len + gridDim.y - 1) / gridDim.y;
+    const int i0 = blockIdx.y * per, i1 = min(len, i0 + per);
     ScanAcc s;
     s.init();
-    for (int i = 0; i < len; ++i) s.add(scale * p[(long long)i * ldv + v]);
-    scan_publish(s, &scale_out[v], info, need_slot);
+    for (int i = i0; i < i1; ++i) s.add(scale * p[(long long)i * ldv + v]);
+    scan_publish(s, &vmax[v], &vlsb[v], info);
+}
+
+__global__ void __launch_bounds__(256) k_scan_init(int nvec, int *vmax, int *vlsb)
+{
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v < nvec) {
+        vmax[v] = -100000;
+        vlsb[v] = 100000;
+    }
+}
+
+// vmax -> scale ea = emax + 1 (in place), and the global slice need / exponent range
+__global__ void __launch_bounds__(256) k_scan_finish(int nvec, int *vmax, const int *vlsb, int *info, int need_slot)
+{
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= nvec) return;
+    const int e = vmax[v];
+    if (e < -50000) {
+        vmax[v] = 0;
+        return;
+    }
+    vmax[v] = e + 1;
+    atomicMax(&info[need_slot], e + 1 - vlsb[v]);
+    atomicMin(&info[INFO_EMIN], e);
+    atomicMax(&info[INFO_EMAX], e);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -207,8 +234,8 @@ __device__ inline double wide_round(const unsigned long long (&in)[4], int unit_
 // ---------------------------------------------------------------------------------------------
 // the kernel: 64x64 outputs per workgroup, each wave a 32x32 quadrant = 2x2 MFMA tiles of 16x16
 // ---------------------------------------------------------------------------------------------
-template <int SA, int SB, int RT>
-__global__ void __launch_bounds__(MF_THREADS, 1) k_gemm_mfma(int ta, int tb, int m, int n, int k, double alpha,
+template <int SA, int SB, int RT, int CT, int WPS>
+__global__ void __launch_bounds__(MF_THREADS, WPS) k_gemm_mfma(int ta, int tb, int m, int n, int k, double alpha,
                                                              const double *__restrict__ a, long long lda,
                                                              const double *__restrict__ b, long long ldb, double beta,
                                                              double *__restrict__ c, long long ldc,
@@ -216,23 +243,25 @@ __global__ void __launch_bounds__(MF_THREADS, 1) k_gemm_mfma(int ta, int tb, int
 {
     constexpr int G = SA + SB - 1;  // accumulator groups d = p+q, d-2 in [0, G)
     constexpr int D = SA + SB;
-    __shared__ double As[SA][MF_KB][MF_LDP];  // [slice][k][row (BM <= 64) + pad]
-    __shared__ double Bs[SB][MF_KB][MF_LDP];
+    __shared__ double As[SA][MF_KB][32 * RT + 16];  // [slice][k][row (BM <= 64) + pad]
+    __shared__ double Bs[SB][MF_KB][32 * CT + 16];  // [slice][k][col (BN <= 64) + pad]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int BM = 32 * RT;
     constexpr int AEPT = BM * MF_KB / MF_THREADS;  // A elements per thread per k-step (4 or 2)
-    const int i0 = blockIdx.y * BM, j0 = blockIdx.x * MF_BN;
-    const int wr = (wave >> 1) * (16 * RT), wc = (wave & 1) * 32;
+    constexpr int BN = 32 * CT;
+    constexpr int BEPT = MF_KB * BN / MF_THREADS;  // B elements per thread per k-step (4 or 2)
+    const int i0 = blockIdx.y * BM, j0 = blockIdx.x * BN;
+    const int wr = (wave >> 1) * (16 * RT), wc = (wave & 1) * (16 * CT);
 
     // global -> register staging: 4 elements of A and 4 of B per thread per k-step
     // A tile 64 rows x 16 k: thread -> (row = tid/4, kq = (tid%4)*4 .. +3); B tile 16 k x 64 cols: (kk = tid/16, cq = (tid%16)*4 .. +3)
     const int ar = tid / (MF_KB / AEPT), akq = (tid % (MF_KB / AEPT)) * AEPT;
-    const int bk = tid >> 4, bcq = (tid & 15) * 4;
+    const int bk = tid / (BN / BEPT), bcq = (tid % (BN / BEPT)) * BEPT;
     const int a_row = i0 + ar;
     const int ea_r = (a_row < m) ? EA[a_row] : 0;
-    int eb_c[4];
+    int eb_c[BEPT];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) eb_c[u] = (j0 + bcq + u < n) ? EB[j0 + bcq + u] : 0;
+    for (int u = 0; u < BEPT; ++u) eb_c[u] = (j0 + bcq + u < n) ? EB[j0 + bcq + u] : 0;
 
     auto load_a = [&](int l0, double (&ra)[AEPT]) {
 #pragma unroll
@@ -243,10 +272,10 @@ __global__ void __launch_bounds__(MF_THREADS, 1) k_gemm_mfma(int ta, int tb, int
             ra[u] = v;
         }
     };
-    auto load_b = [&](int l0, double (&rb)[4]) {
+    auto load_b = [&](int l0, double (&rb)[BEPT]) {
         const int gl = l0 + bk;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < BEPT; ++u) {
             const int gj = j0 + bcq + u;
             double v = 0.0;
             if (gl < k && gj < n) v = tb ? b[(long long)gj * ldb + gl] : b[(long long)gl * ldb + gj];
@@ -254,27 +283,27 @@ __global__ void __launch_bounds__(MF_THREADS, 1) k_gemm_mfma(int ta, int tb, int
         }
     };
 
-    unsigned long long wide[RT][2][4][4];  // [row tile][col tile][reg][limb]
+    unsigned long long wide[RT][CT][4][4];  // [row tile][col tile][reg][limb]
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
+        for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int w = 0; w < 4; ++w) wide[rt][ct][r][w] = 0ull;
 
-    double ra[AEPT], rb[4];
+    double ra[AEPT], rb[BEPT];
     load_a(0, ra);
     load_b(0, rb);
     for (int kb = 0; kb < k; kb += MF_KP) {
-        v4d_t acc[G][RT][2];
+        v4d_t acc[G][RT][CT];
 #pragma unroll
         for (int g = 0; g < G; ++g)
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-                for (int ct = 0; ct < 2; ++ct) acc[g][rt][ct] = (v4d_t){0.0, 0.0, 0.0, 0.0};
+                for (int ct = 0; ct < CT; ++ct) acc[g][rt][ct] = (v4d_t){0.0, 0.0, 0.0, 0.0};
         const int kend = min(k, kb + MF_KP);
         for (int l0 = kb; l0 < kend; l0 += MF_KB) {
             __syncthreads();  // previous step's fragments consumed
@@ -286,7 +315,7 @@ __global__ void __launch_bounds__(MF_THREADS, 1) k_gemm_mfma(int ta, int tb, int
                 for (int p = 0; p < SA; ++p) As[p][akq + u][ar] = sa[p];
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < BEPT; ++u) {
                 double sb[SB];
                 slice<SB>(rb[u], eb_c[u], sb);
 #pragma unroll
@@ -301,14 +330,14 @@ __global__ void __launch_bounds__(MF_THREADS, 1) k_gemm_mfma(int ta, int tb, int
             __syncthreads();
 #pragma unroll
             for (int kk = 0; kk < MF_KB; kk += 4) {
-                double fa[RT][SA], fb[2][SB];
+                double fa[RT][SA], fb[CT][SB];
                 const int kx = kk + (lane >> 4);
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
                     for (int p = 0; p < SA; ++p) fa[rt][p] = As[p][kx][wr + rt * 16 + (lane & 15)];
 #pragma unroll
-                for (int ct = 0; ct < 2; ++ct)
+                for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
                     for (int q = 0; q < SB; ++q) fb[ct][q] = Bs[q][kx][wc + ct * 16 + (lane & 15)];
 #pragma unroll
@@ -318,7 +347,7 @@ __global__ void __launch_bounds__(MF_THREADS, 1) k_gemm_mfma(int ta, int tb, int
 #pragma unroll
                         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-                            for (int ct = 0; ct < 2; ++ct)
+                            for (int ct = 0; ct < CT; ++ct)
                                 acc[p + q][rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[rt][p], fb[ct][q],
                                                                                           acc[p + q][rt][ct], 0, 0, 0);
             }
@@ -330,7 +359,7 @@ __global__ void __launch_bounds__(MF_THREADS, 1) k_gemm_mfma(int ta, int tb, int
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-                for (int ct = 0; ct < 2; ++ct)
+                for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         wide_add<MF_BETA * (D - (g + 2))>(wide[rt][ct][r], __double2ll_rn(acc[g][rt][ct][r]));
@@ -340,7 +369,7 @@ __global__ void __launch_bounds__(MF_THREADS, 1) k_gemm_mfma(int ta, int tb, int
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
+        for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int gi = i0 + wr + rt * 16 + (lane >> 4) + 4 * r;
@@ -353,13 +382,14 @@ __global__ void __launch_bounds__(MF_THREADS, 1) k_gemm_mfma(int ta, int tb, int
             }
 }
 
-template <int SA, int SB, int RT>
+template <int SA, int SB, int RT, int CT, int WPS>
 static void launch_mfma(int ta, int tb, int m, int n, int k, double alpha, const double *a, int lda, const double *b,
                         int ldb, double beta, double *c, int ldc, const int *EA, const int *EB, hipStream_t st)
 {
     constexpr int BM = 32 * RT;
-    dim3 grid((n + MF_BN - 1) / MF_BN, (m + BM - 1) / BM);
-    hipLaunchKernelGGL((k_gemm_mfma<SA, SB, RT>), grid, dim3(MF_THREADS), 0, st, ta, tb, m, n, k, alpha, a, (long long)lda,
+    constexpr int BN = 32 * CT;
+    dim3 grid((n + BN - 1) / BN, (m + BM - 1) / BM);
+    hipLaunchKernelGGL((k_gemm_mfma<SA, SB, RT, CT, WPS>), grid, dim3(MF_THREADS), 0, st, ta, tb, m, n, k, alpha, a, (long long)lda,
                        b, (long long)ldb, beta, c, (long long)ldc, EA, EB);
 }
 
@@ -372,22 +402,26 @@ bool exgemm_try_mfma(Ctx &c, char transa, char transb, int m, int n, int k, doub
     c.last_gemm_slices = 0;
     if (k <= 0) return false;
     const int ta = (transa == 'T' || transa == 't'), tb = (transb == 'T' || transb == 't');
-    int *buf = (int *)workspace(c, sizeof(int) * ((size_t)m + n + INFO_WORDS));
-    int *info = buf, *EA = buf + INFO_WORDS, *EB = EA + m;
+    int *buf = (int *)workspace(c, sizeof(int) * (2 * ((size_t)m + n) + INFO_WORDS));
+    int *info = buf, *EA = buf + INFO_WORDS, *EB = EA + m, *LA = EB + n, *LB = LA + m;
     const int init[INFO_WORDS] = {0, 0, 0, 100000, -100000, 0, 0, 0};
     if ((*err = hipMemcpyAsync(info, init, sizeof(init), hipMemcpyHostToDevice, st)) != hipSuccess) return true;
+    hipLaunchKernelGGL(k_scan_init, dim3((m + n + 255) / 256), dim3(256), 0, st, m + n, EA, LA);  // EA|EB and LA|LB are contiguous
+    const int ysplit = k >= 2048 ? 32 : (k >= 256 ? 8 : 1);
     // rows of A' (reduction over l)
     if (!ta)
-        hipLaunchKernelGGL(k_scan_contig, dim3(m), dim3(256), 0, st, a, (long long)lda, m, k, alpha, EA, info, INFO_NEED_A);
+        hipLaunchKernelGGL(k_scan_contig, dim3(m), dim3(256), 0, st, a, (long long)lda, m, k, alpha, EA, LA, info);
     else
-        hipLaunchKernelGGL(k_scan_strided, dim3((m + 255) / 256), dim3(256), 0, st, a, (long long)lda, m, k, alpha, EA, info,
-                           INFO_NEED_A);
+        hipLaunchKernelGGL(k_scan_strided, dim3((m + 255) / 256, ysplit), dim3(256), 0, st, a, (long long)lda, m, k, alpha,
+                           EA, LA, info);
     // columns of B (reduction over l)
     if (!tb)
-        hipLaunchKernelGGL(k_scan_strided, dim3((n + 255) / 256), dim3(256), 0, st, b, (long long)ldb, n, k, 1.0, EB, info,
-                           INFO_NEED_B);
+        hipLaunchKernelGGL(k_scan_strided, dim3((n + 255) / 256, ysplit), dim3(256), 0, st, b, (long long)ldb, n, k, 1.0,
+                           EB, LB, info);
     else
-        hipLaunchKernelGGL(k_scan_contig, dim3(n), dim3(256), 0, st, b, (long long)ldb, n, k, 1.0, EB, info, INFO_NEED_B);
+        hipLaunchKernelGGL(k_scan_contig, dim3(n), dim3(256), 0, st, b, (long long)ldb, n, k, 1.0, EB, LB, info);
+    hipLaunchKernelGGL(k_scan_finish, dim3((m + 255) / 256), dim3(256), 0, st, m, EA, LA, info, INFO_NEED_A);
+    hipLaunchKernelGGL(k_scan_finish, dim3((n + 255) / 256), dim3(256), 0, st, n, EB, LB, info, INFO_NEED_B);
     int h[INFO_WORDS];
     if ((*err = hipMemcpyAsync(h, info, sizeof(h), hipMemcpyDeviceToHost, st)) != hipSuccess) return true;
     if ((*err = hipStreamSynchronize(st)) != hipSuccess) return true;
@@ -398,11 +432,22 @@ bool exgemm_try_mfma(Ctx &c, char transa, char transb, int m, int n, int k, doub
     const int s = sa > sb ? sa : sb;
     if (s > 4 || s < 1) return false;
     // k-blocks: (k / KP) * G * 2^53 must fit the 256-bit accumulator: 53 + BETA*(2S-2) + log2(k/KP * G) < 255
-#define MF_GO(S, RT) launch_mfma<S, S, RT>(ta, tb, m, n, k, alpha, a, lda, b, ldb, beta, cmat, ldc, EA, EB, st)
+#define MF_GO(S, RT, CT, WPS) \
+    launch_mfma<S, S, RT, CT, WPS>(ta, tb, m, n, k, alpha, a, lda, b, ldb, beta, cmat, ldc, EA, EB, st)
+    // wave tile RT x CT and waves/SIMD: chosen by A/B on MI355X (tools/bench_gemm.py); c.variant selects the others
     switch (s) {
-    case 1: case 2: MF_GO(2, 2); break;
-    case 3: MF_GO(3, 2); break;
-    default: MF_GO(4, 1); break;
+    case 1: case 2:
+        if (c.variant == 1) MF_GO(2, 2, 2, 1); else MF_GO(2, 1, 2, 2);
+        break;
+    case 3:
+        if (c.variant == 1) MF_GO(3, 2, 2, 1);
+        else if (c.variant == 2) MF_GO(3, 1, 1, 4);
+        else if (c.variant == 3) MF_GO(3, 1, 1, 3);
+        else MF_GO(3, 1, 2, 2);
+        break;
+    default:
+        if (c.variant == 2) MF_GO(4, 1, 1, 2); else MF_GO(4, 1, 2, 1);
+        break;
     }
 #undef MF_GO
     c.last_gemm_slices = s < 2 ? 2 : s;
