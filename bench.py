@@ -61,8 +61,8 @@ def timed_steps(ex, torch, dist, op, tensors, fpe, ee, steps, warmup, world, rec
         if e1 is not None:
             e1.record()
         ex.finish_dev(out=rec)
-        if world > 1:
-            ex.allreduce_record(rec)
+        if world > 1 or (dist is not None and dist.is_initialized()):
+            ex.allreduce_record(rec, force=True)
             ex.finalize_dev(rec[ex.OUT_DIGITS:ex.OUT_DIGITS + ex.SET_WORDS], out=rec)
 
     t_pre = time.perf_counter()
@@ -174,7 +174,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    force_dist = os.environ.get("EXBLAS_BENCH_FORCE_DIST") == "1"  # rehearse the RCCL path with a 1-rank group
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
@@ -288,7 +289,7 @@ def main():
             out["cpu_baseline"] = base
             out["bit_exact_vs_cpu"] = ok
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist is not None and dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

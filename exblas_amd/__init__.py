@@ -29,7 +29,7 @@ C_ABI_SYMBOLS = [
     "exblas_exgemm_dev", "exblas_gen_dev", "exblas_stream_read_dev", "exblas_exsum", "exblas_exdot",
     "exblas_exgemv", "exblas_exgemm", "exblas_exsum_record", "exblas_exdot_record",
     "exblas_exsum_accumulate_dev", "exblas_exdot_accumulate_dev", "exblas_finish_dev", "exblas_set_tuning",
-    "exblas_set_gemm_path", "exblas_last_gemm_slices",
+    "exblas_set_gemm_path", "exblas_last_gemm_slices", "exblas_exsum_segmented_dev",
 ]
 
 _lib = None
@@ -71,6 +71,7 @@ def load_library():
     L.exblas_exsum_accumulate_dev.argtypes = [vp, i64, i64, i32, i32, vp]
     L.exblas_exdot_accumulate_dev.argtypes = [vp, i64, vp, i64, i64, i32, i32, vp]
     L.exblas_finish_dev.argtypes = [vp, vp]
+    L.exblas_exsum_segmented_dev.argtypes = [vp, vp, i64, i32, i32, vp, vp]
     L.exblas_exgemv_dev.argtypes = [C.c_char, i32, i32, dbl, vp, i32, vp, i32, dbl, vp, i32, i32, i32, vp]
     L.exblas_exgemm_dev.argtypes = [C.c_char, C.c_char, i32, i32, i32, dbl, vp, i32, vp, i32, dbl, vp, i32, i32,
                                     i32, vp]
@@ -185,6 +186,19 @@ def finish_dev(out=None):
     if out is None:
         out = new_record_buffer()
     _check(load_library().exblas_finish_dev(_stream_ptr(torch), C.c_void_p(out.data_ptr())), "finish_dev")
+    return out
+
+
+def exsum_segmented_dev(values, offsets, fpe=8, early_exit=True, out=None):
+    """out[s] = exact sum of values[offsets[s]:offsets[s+1]] (CUDA float64 / int64 tensors), one launch."""
+    torch = _require_gpu()
+    assert values.is_cuda and values.dtype == torch.float64 and offsets.is_cuda and offsets.dtype == torch.int64
+    nseg = offsets.numel() - 1
+    if out is None:
+        out = torch.empty(max(nseg, 0), dtype=torch.float64, device="cuda")
+    _check(load_library().exblas_exsum_segmented_dev(C.c_void_p(values.data_ptr()), C.c_void_p(offsets.data_ptr()),
+                                                     nseg, fpe, int(early_exit), _stream_ptr(torch),
+                                                     C.c_void_p(out.data_ptr())), "exsum_segmented_dev")
     return out
 
 

@@ -331,6 +331,46 @@ __global__ void __launch_bounds__(128) k_finalize(long long *sets, int nsets, in
 }
 
 // ---------------------------------------------------------------------------------------------
+// Segmented ExSUM: out[s] = Round(sum values[offsets[s] .. offsets[s+1])), one wave per segment, four
+// segments per workgroup.  This is the batched form of the call pattern of the reference's SpMV example, which
+// runs one exsum per matrix row on a short vector of products (src/cpu/examples/spmv (Parboil)/
+// StrongReproducibility/main.cpp:85): thousands of tiny reductions cost one launch instead of one each.
+// ---------------------------------------------------------------------------------------------
+template <int N, bool EE>
+__global__ void __launch_bounds__(BLOCK) k_exsum_segmented(const double *__restrict__ values,
+                                                           const long long *__restrict__ offsets, long long nseg,
+                                                           int round_mode, double *__restrict__ out)
+{
+    __shared__ FinishShared fs[WAVES];
+    __shared__ unsigned fl[WAVES];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long long seg = (long long)blockIdx.x * WAVES + w;
+    const bool valid = seg < nseg;
+    for (int t = lane; t < NL; t += 64) fs[w].v[t] = 0;
+    if (lane == 0) fl[w] = 0;
+    __syncthreads();
+    if (valid) {
+        unsigned flags = 0;
+        LdsSink<1> sink{fs[w].v, flags};
+        double fpe[N > 0 ? N : 1];
+#pragma unroll
+        for (int i = 0; i < (N > 0 ? N : 1); ++i) fpe[i] = 0.0;
+        const long long b = offsets[seg], e = offsets[seg + 1];
+        // all lanes run the same number of iterations (the early-exit vote is wave-wide); lanes past the end add 0
+        for (long long i0 = b; i0 < e; i0 += 64) {
+            const long long i = i0 + lane;
+            double x[1] = {i < e ? values[i] : 0.0};
+            fpe_absorb_sink<N, EE, 1>(fpe, x, 0, sink);
+        }
+        fpe_flush_sink<N>(fpe, sink);
+        if (flags) atomicOr(&fl[w], flags);
+    }
+    __syncthreads();
+    finish_core<64>(fs[w], lane, fl[w]);
+    if (valid && lane == 0) out[seg] = round_mode ? fs[w].rf : __longlong_as_double((long long)fs[w].ex);
+}
+
+// ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
 static inline int grid_for(const Ctx &c, long long work_items, long long per_block, int blocks_per_cu)
@@ -452,6 +492,36 @@ hipError_t exsum_dispatch(Ctx &c, const double *a, long long n, long long inca, 
     }
     *supported = false;  // the reference silently returns 0.0 (gpu:ExSUM.cpp:83)
     return hipSuccess;
+}
+
+// same variant rules as exsum (gpu:ExSUM.cpp:64-84); an unsupported combination yields 0.0 for every segment
+hipError_t exsum_segmented_dispatch(const double *values, const long long *offsets, long long nseg, int fpe,
+                                    int early_exit, int round_mode, hipStream_t st, double *out)
+{
+    if (nseg <= 0) return hipSuccess;
+    const dim3 grid((unsigned)((nseg + WAVES - 1) / WAVES)), block(BLOCK);
+#define SEG_GO(N, EE) \
+    hipLaunchKernelGGL((k_exsum_segmented<N, EE>), grid, block, 0, st, values, offsets, nseg, round_mode, out)
+    if (fpe < 2) SEG_GO(0, false);
+    else if (early_exit) {
+        if (fpe <= 4) SEG_GO(4, true);
+        else if (fpe <= 6) SEG_GO(6, true);
+        else if (fpe <= 8) SEG_GO(8, true);
+        else return hipMemsetAsync(out, 0, sizeof(double) * nseg, st);
+    } else {
+        switch (fpe) {
+        case 2: SEG_GO(2, false); break;
+        case 3: SEG_GO(3, false); break;
+        case 4: SEG_GO(4, false); break;
+        case 5: SEG_GO(5, false); break;
+        case 6: SEG_GO(6, false); break;
+        case 7: SEG_GO(7, false); break;
+        case 8: SEG_GO(8, false); break;
+        default: return hipMemsetAsync(out, 0, sizeof(double) * nseg, st);
+        }
+    }
+#undef SEG_GO
+    return hipGetLastError();
 }
 
 // ExDOT.cpp:69-98 (fpe < 3 -> superaccumulators only)

@@ -315,6 +315,15 @@ int exblas_exdot_dev(const double *d_a, int64_t inca, const double *d_b, int64_t
     return rc ? rc : exblas_finish_dev(stream, d_out);
 }
 
+int exblas_exsum_segmented_dev(const double *d_values, const int64_t *d_offsets, int64_t nseg, int fpe, int early_exit,
+                               void *stream, double *d_out)
+{
+    if (fpe < 0) return (int)hipErrorInvalidValue;
+    ctx(-1);
+    return (int)exsum_segmented_dispatch(d_values, (const long long *)d_offsets, nseg, fpe, early_exit, round_mode(),
+                                         (hipStream_t)stream, d_out);
+}
+
 int exblas_finalize_dev(const int64_t *d_digit_sets, int nsets, uint32_t flags_or, void *stream, int64_t *d_out)
 {
     ctx(-1);

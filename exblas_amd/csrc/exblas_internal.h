@@ -51,6 +51,8 @@ hipError_t exsum_dispatch(Ctx &c, const double *a, long long n, long long inca, 
                           hipStream_t st, bool *supported);
 hipError_t exdot_dispatch(Ctx &c, const double *a, long long inca, const double *b, long long incb, long long n,
                           int fpe, int early_exit, hipStream_t st, bool *supported);
+hipError_t exsum_segmented_dispatch(const double *values, const long long *offsets, long long nseg, int fpe,
+                                    int early_exit, int round_mode, hipStream_t st, double *out);
 hipError_t finalize_groups(Ctx &c, hipStream_t st, long long *d_out);
 hipError_t finalize_sets(const long long *d_sets, int nsets, unsigned flags_or, hipStream_t st, long long *d_out);
 

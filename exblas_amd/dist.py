@@ -19,13 +19,13 @@ def shard_range(n, rank, world):
     return cut(rank), cut(rank + 1)
 
 
-def allreduce_record(rec, group=None):
+def allreduce_record(rec, group=None, force=False):
     """In-place int64 SUM all-reduce of the digit set (words 48..119) of a record tensor.
 
     Works on any device/back-end pair torch.distributed supports (nccl=RCCL on GPUs, gloo on CPU)."""
     import torch.distributed as dist
     payload = rec[OUT_DIGITS:OUT_DIGITS + SET_WORDS]
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized() and (force or dist.get_world_size(group) > 1):
         dist.all_reduce(payload, op=dist.ReduceOp.SUM, group=group)
     return rec
 

@@ -78,6 +78,12 @@ int exblas_exsum_dev(const double *d_a, int64_t n, int64_t inca, int fpe, int ea
  * ExDOTComplete (ExDOT.Superacc.cl:217-359, ExDOT.FPE.cl:201-345); variants as ExDOT.cpp:69-98. */
 int exblas_exdot_dev(const double *d_a, int64_t inca, const double *d_b, int64_t incb, int64_t n,
                      int fpe, int early_exit, void *stream, int64_t *d_out);
+/* Segmented (batched) ExSUM: d_out[s] = correctly rounded sum of d_values[d_offsets[s] .. d_offsets[s+1]) for
+ * s < nseg, all in one launch (one wavefront per segment).  The batched form of what the reference's examples do
+ * with one exsum() call per CSR row (src/cpu/examples/spmv (Parboil)/StrongReproducibility/main.cpp:85).
+ * Rounding mode as set by exblas_set_round_mode / EXBLAS_ROUND. */
+int exblas_exsum_segmented_dev(const double *d_values, const int64_t *d_offsets, int64_t nseg, int fpe,
+                               int early_exit, void *stream, double *d_out);
 /* The two phases of the calls above, separately: *_accumulate_dev launches only the streaming kernel
  * and adds its result into the context's (zero-initialised) accumulators, so several arrays can be
  * folded into ONE exact sum; exblas_finish_dev carry-propagates, rounds, writes the record and

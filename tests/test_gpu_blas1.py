@@ -174,3 +174,18 @@ def test_concurrent_cpp_callers(ex):
     subprocess.run(["make", "-C", os.path.join(root, "tests", "cpp")], check=True, capture_output=True)
     r = subprocess.run([os.path.join(root, "tests", "cpp", "test_threads")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "TestPassed; ALL OK!" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+def test_exsum_segmented(ex, oracle):
+    """Batched exsum over CSR-style segments (empty, 1-element, ragged, longer than a wave) vs the oracle per segment."""
+    import torch
+    rng = np.random.default_rng(3)
+    lens = np.concatenate([[0, 1, 2, 63, 64, 65, 0, 1000, 5000], rng.integers(0, 200, 500)])
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    for kind, p0, p1 in (("ill_cond", 1e32, 0.0), ("lognormal", 0.0, 50.0), ("fpuniform_signed", 1500.0, 700.0)):
+        vals = oracle.gen(kind, int(offs[-1]), 17, p0, p1)
+        want = np.array([oracle.exsum(vals[offs[i]:offs[i + 1]], 0) if lens[i] else 0.0 for i in range(len(lens))])
+        dv, do = torch.from_numpy(vals).cuda(), torch.from_numpy(offs).cuda()
+        for fpe, ee in FPE_VARIANTS_SUM:
+            got = ex.exsum_segmented_dev(dv, do, fpe, ee).cpu().numpy()
+            assert (got.view(np.int64) == want.view(np.int64)).all(), (kind, fpe, ee, np.nonzero(got != want)[0][:5])
