@@ -83,6 +83,8 @@ __global__ void __launch_bounds__(BLOCK) k_exsum(const double *__restrict__ a, l
     const long long nv = (n - head) >> 1;
     constexpr long long TILE = (long long)BLOCK * U;
     const long long ntiles = nv / TILE;
+    LdsSink<COPIES> sinkm{col, flags};
+    int bypass = 0;
 
     if constexpr (!PF) {
         for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
@@ -96,7 +98,7 @@ __global__ void __launch_bounds__(BLOCK) k_exsum(const double *__restrict__ a, l
                 x[2 * u] = r[u].x;
                 x[2 * u + 1] = r[u].y;
             }
-            fpe_absorb<N, EE, COPIES, 2 * U, ZM>(fpe, x, 0, col, flags);
+            fpe_absorb_adaptive<N, EE, 2 * U, LdsSink<COPIES>, ZM>(fpe, x, sinkm, bypass);
         }
     } else {
         // register double-buffering: the next tile's loads are in flight while this one is absorbed.
@@ -128,7 +130,7 @@ __global__ void __launch_bounds__(BLOCK) k_exsum(const double *__restrict__ a, l
 #pragma unroll
                 for (int u = 0; u < U; ++u) r[u] = ld2<NT>(p + u * BLOCK);
             }
-            fpe_absorb<N, EE, COPIES, 2 * U, ZM>(fpe, x, 0, col, flags);
+            fpe_absorb_adaptive<N, EE, 2 * U, LdsSink<COPIES>, ZM>(fpe, x, sinkm, bypass);
             t = tn;
         }
     }
@@ -194,6 +196,7 @@ __global__ void __launch_bounds__(BLOCK) k_exdot(const double *__restrict__ a, c
     // vector path only when both streams are 16-byte aligned (host guarantees or falls to strided)
     const d2_t *va = (const d2_t *)a, *vb = (const d2_t *)b;
     const long long nv = n >> 1;
+    int bypass = 0;
     constexpr long long TILE = (long long)BLOCK * U;
     const long long ntiles = nv / TILE;
     if constexpr (!PF) {
@@ -211,7 +214,7 @@ __global__ void __launch_bounds__(BLOCK) k_exdot(const double *__restrict__ a, c
                 x[2 * u] = two_prod(ra[u].x, rb[u].x, e[2 * u]);
                 x[2 * u + 1] = two_prod(ra[u].y, rb[u].y, e[2 * u + 1]);
             }
-            fpe_absorb_prod<N, EE, 2 * U>(fpe, x, e, sink);
+            fpe_absorb_prod_adaptive<N, EE, 2 * U>(fpe, x, e, sink, bypass);
         }
     } else {
         long long t = blockIdx.x;
@@ -240,7 +243,7 @@ __global__ void __launch_bounds__(BLOCK) k_exdot(const double *__restrict__ a, c
                     rb[u] = ld2<NT>(vb + base + u * BLOCK);
                 }
             }
-            fpe_absorb_prod<N, EE, 2 * U>(fpe, x, e, sink);
+            fpe_absorb_prod_adaptive<N, EE, 2 * U>(fpe, x, e, sink, bypass);
             t = tn;
         }
     }
@@ -384,7 +387,7 @@ static inline int grid_for(const Ctx &c, long long work_items, long long per_blo
 template <int N, bool EE, int COPIES, int U, bool NT, bool PF, int ZM = 0>
 static void run_exsum(Ctx &c, const double *a, long long n, hipStream_t st)
 {
-    int grid = grid_for(c, n, (long long)BLOCK * 2 * U, c.bpc_sum);
+    int grid = grid_for(c, n, (long long)BLOCK * 2 * U, N == 0 ? c.bpc_sa : c.bpc_sum);
     hipLaunchKernelGGL((k_exsum<N, EE, COPIES, U, NT, PF, ZM>), dim3(grid), dim3(BLOCK), 0, st, a, n, c.gacc, c.gflags,
                        c.ngroups, c.variant == 9 ? 1 : 0);
 }

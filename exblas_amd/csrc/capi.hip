@@ -75,7 +75,8 @@ Ctx &ctx(int device)
         c.num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         c.blocks_per_cu = env_int("EXBLAS_BLOCKS_PER_CU", 8);
         c.bpc_sum = env_int("EXBLAS_BPC_SUM", 2);
-        c.bpc_dot = env_int("EXBLAS_BPC_DOT", 16);
+        c.bpc_dot = env_int("EXBLAS_BPC_DOT", 32);
+        c.bpc_sa = env_int("EXBLAS_BPC_SA", 3);
         c.ngroups = env_int("EXBLAS_NGROUPS", 32);
         if (c.ngroups < 1) c.ngroups = 1;
         c.variant = env_int("EXBLAS_VARIANT", 0);
@@ -251,7 +252,7 @@ int exblas_set_tuning(int blocks_per_cu, int ngroups, int variant)
 {
     Ctx &c = ctx(-1);
     std::lock_guard<std::mutex> lk(c.mu);
-    if (blocks_per_cu > 0) c.blocks_per_cu = c.bpc_sum = c.bpc_dot = blocks_per_cu;
+    if (blocks_per_cu > 0) c.blocks_per_cu = c.bpc_sum = c.bpc_dot = c.bpc_sa = blocks_per_cu;
     if (ngroups > 0 && ngroups != c.ngroups) {
         EXB_CHECK(hipDeviceSynchronize());
         EXB_CHECK(hipFree(c.gacc));

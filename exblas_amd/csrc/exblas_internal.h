@@ -15,7 +15,8 @@ struct Ctx {
     int blocks_per_cu = 8;   // EXBLAS_BLOCKS_PER_CU: generic cap of resident blocks per CU
     // Measured on MI355X (tools/tune.py, n = 2^28): the one-stream ExSUM kernel is fastest with FEW fat
     // blocks (2 per CU: 7.15 TB/s vs 6.46 at 8), the two-stream ExDOT kernel with many (16-32 per CU).
-    int bpc_sum = 2, bpc_dot = 16;
+    int bpc_sum = 2, bpc_dot = 32;
+    int bpc_sa = 3;          // superaccumulator-only ExSUM (LDS-atomic bound; 3/CU: 6.65 TB/s, 2/CU: 6.0)
     int ngroups = 32;        // EXBLAS_NGROUPS: global group accumulators the blocks add into
     int variant = 0;         // tuning variant of the production kernels (exblas_set_tuning)
     int last_gemm_slices = 0;  // 0: the last exgemm ran the scalar kernel; 2..4: MFMA path with that many slices

@@ -108,8 +108,9 @@ __device__ __forceinline__ void fpe_guard(double &a0, double (&x)[CNT], double *
 
 // Push CNT elements (a "tile") through expansion levels from..N-1.  EE: one wave-uniform test per
 // level per tile ends the cascade as soon as every residue of every lane is zero.
+// Returns (wave-uniform) whether anything had to be spilled to the integer accumulator.
 template <int N, bool EE, int CNT, class Sink, int ZM = 0>
-__device__ __forceinline__ void fpe_cascade(double (&a)[N > 0 ? N : 1], double (&x)[CNT], int from, Sink &sink)
+__device__ __forceinline__ bool fpe_cascade(double (&a)[N > 0 ? N : 1], double (&x)[CNT], int from, Sink &sink)
 {
     bool live = true;
 #pragma unroll
@@ -125,29 +126,55 @@ __device__ __forceinline__ void fpe_cascade(double (&a)[N > 0 ? N : 1], double (
         }
     }
     // what survived every level goes to the integer accumulator (rare: one wave-uniform test first)
-    if (live && __any(any_nonzero<CNT, ZM>(x))) {
+    const bool spill = live && __any(any_nonzero<CNT, ZM>(x));
+    if (spill) {
 #pragma unroll
         for (int j = 0; j < CNT; ++j)
             if (x[j] != 0.0) sink.add(x[j]);
     }
+    return spill;
 }
 
 template <int N, bool EE, int CNT, class Sink, int ZM = 0>
-__device__ __forceinline__ void fpe_absorb_sink(double (&a)[N > 0 ? N : 1], double (&x)[CNT], int from, Sink &sink)
+__device__ __forceinline__ bool fpe_absorb_sink(double (&a)[N > 0 ? N : 1], double (&x)[CNT], int from, Sink &sink)
 {
     if constexpr (N == 0) {
 #pragma unroll
         for (int j = 0; j < CNT; ++j) sink.add(x[j]);
+        return false;
     } else {
         if (from == 0) fpe_guard<CNT>(a[0], x, nullptr, sink);
-        fpe_cascade<N, EE, CNT, Sink, ZM>(a, x, from, sink);
+        return fpe_cascade<N, EE, CNT, Sink, ZM>(a, x, from, sink);
+    }
+}
+
+// Adaptive front-end of the early-exit variants.  When a tile had to spill (its residues outlived all N levels:
+// the data's exponent range is wider than the expansion can hold), the next BYPASS_TILES tiles skip the expansion
+// and go straight to the integer accumulator -- which on gfx950 streams at ~6 TB/s on its own -- before the
+// expansion is tried again.  Wide-range inputs then cost about what the superaccumulator-only variant costs instead
+// of N TwoSum levels PLUS the spill per element; well-conditioned inputs never take the branch.  Exact either way.
+constexpr int BYPASS_TILES = 63;
+
+template <int N, bool EE, int CNT, class Sink, int ZM = 0>
+__device__ __forceinline__ void fpe_absorb_adaptive(double (&a)[N > 0 ? N : 1], double (&x)[CNT], Sink &sink, int &bypass)
+{
+    if constexpr (N == 0 || !EE) {
+        fpe_absorb_sink<N, EE, CNT, Sink, ZM>(a, x, 0, sink);
+    } else {
+        if (bypass > 0) {  // wave-uniform
+            --bypass;
+#pragma unroll
+            for (int j = 0; j < CNT; ++j) sink.add(x[j]);
+        } else if (fpe_absorb_sink<N, EE, CNT, Sink, ZM>(a, x, 0, sink)) {
+            bypass = BYPASS_TILES;
+        }
     }
 }
 
 // Products: p[j] + e[j] = a_j * b_j exactly (two_prod, NOT the _safe form: the guard handles overflow).
 // The rounding errors enter the expansion at slot max(N-3, 0) like ExDOT.FPE.cl:254.
 template <int N, bool EE, int CNT, class Sink>
-__device__ __forceinline__ void fpe_absorb_prod(double (&a)[N > 0 ? N : 1], double (&p)[CNT], double (&e)[CNT],
+__device__ __forceinline__ bool fpe_absorb_prod(double (&a)[N > 0 ? N : 1], double (&p)[CNT], double (&e)[CNT],
                                                 Sink &sink)
 {
     if constexpr (N == 0) {
@@ -156,11 +183,34 @@ __device__ __forceinline__ void fpe_absorb_prod(double (&a)[N > 0 ? N : 1], doub
             sink.add(p[j]);
             if (e[j] != 0.0 && expo_field(p[j]) != 0x7ffu) sink.add(e[j]);
         }
+        return false;
     } else {
         constexpr int EFROM = (N >= 3) ? N - 3 : 0;
         fpe_guard<CNT>(a[0], p, e, sink);
-        fpe_cascade<N, EE, CNT>(a, p, 0, sink);
-        fpe_cascade<N, EE, CNT>(a, e, EFROM, sink);
+        const bool s1 = fpe_cascade<N, EE, CNT>(a, p, 0, sink);
+        const bool s2 = fpe_cascade<N, EE, CNT>(a, e, EFROM, sink);
+        return s1 || s2;
+    }
+}
+
+// adaptive form for products (see fpe_absorb_adaptive)
+template <int N, bool EE, int CNT, class Sink>
+__device__ __forceinline__ void fpe_absorb_prod_adaptive(double (&a)[N > 0 ? N : 1], double (&p)[CNT],
+                                                         double (&e)[CNT], Sink &sink, int &bypass)
+{
+    if constexpr (N == 0 || !EE) {
+        fpe_absorb_prod<N, EE, CNT>(a, p, e, sink);
+    } else {
+        if (bypass > 0) {
+            --bypass;
+#pragma unroll
+            for (int j = 0; j < CNT; ++j) {
+                sink.add(p[j]);
+                if (e[j] != 0.0 && expo_field(p[j]) != 0x7ffu) sink.add(e[j]);
+            }
+        } else if (fpe_absorb_prod<N, EE, CNT>(a, p, e, sink)) {
+            bypass = BYPASS_TILES;
+        }
     }
 }
 

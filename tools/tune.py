@@ -15,10 +15,15 @@ log2n = int(sys.argv[2]) if len(sys.argv) > 2 else 28
 variants = [int(v) for v in os.environ.get("TUNE_VARIANTS", "0,1,2,3,4,5").split(",")]
 bpcs = [int(v) for v in os.environ.get("TUNE_BPC", "4,8,16").split(",")]
 rounds = int(os.environ.get("TUNE_ROUNDS", "7"))
+fpe = int(os.environ.get("TUNE_FPE", "8"))
+ee = os.environ.get("TUNE_EE", "1") == "1"
+kind = os.environ.get("TUNE_KIND", "ill_cond")
+p0 = float(os.environ.get("TUNE_P0", "1e32"))
+p1 = float(os.environ.get("TUNE_P1", "0"))
 n = 1 << log2n
 lib = ex.load_library()
-x = ex.gen_dev("ill_cond", n, 1, 1e32)
-y = ex.gen_dev("ill_cond", n, 2, 1e32) if op == "exdot" else None
+x = ex.gen_dev(kind, n, 1, p0, p1)
+y = ex.gen_dev(kind, n, 2, p0, p1) if op == "exdot" else None
 rec = ex.new_record_buffer()
 bpe = 8 if op == "exsum" else 16
 cfgs = [(v, b) for v in variants for b in bpcs]
@@ -32,9 +37,9 @@ for r in range(rounds + 1):
         e0.record()
         for _ in range(reps):
             if op == "exsum":
-                ex.exsum_accumulate_dev(x, 8, True)
+                ex.exsum_accumulate_dev(x, fpe, ee)
             else:
-                ex.exdot_accumulate_dev(x, y, 8, True)
+                ex.exdot_accumulate_dev(x, y, fpe, ee)
         e1.record()
         ex.finish_dev(out=rec)
         torch.cuda.synchronize()
