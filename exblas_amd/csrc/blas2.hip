@@ -212,6 +212,7 @@ __global__ void __launch_bounds__(GV_BLOCK) k_gemvT(int m, double alpha, const d
 
     const bool vec = incx == 1 && ((((uintptr_t)col) | ((uintptr_t)x)) & 15u) == 0;
     long long done = 0;
+    int bypass = 0;
     if (vec) {
         constexpr int U = 2;
         const d2_t *va = (const d2_t *)col, *vx = (const d2_t *)x;
@@ -230,7 +231,7 @@ __global__ void __launch_bounds__(GV_BLOCK) k_gemvT(int m, double alpha, const d
                 p[2 * u] = two_prod(ra[u].x, alpha * rx[u].x, e[2 * u]);
                 p[2 * u + 1] = two_prod(ra[u].y, alpha * rx[u].y, e[2 * u + 1]);
             }
-            fpe_absorb_prod<N, EE, 2 * U>(f, p, e, sink);
+            fpe_absorb_prod_adaptive<N, EE, 2 * U>(f, p, e, sink, bypass);
         }
         done = ntiles * tile * 2;
     }

@@ -38,6 +38,7 @@ __global__ void __launch_bounds__(GM_THREADS) k_gemm(int ta, int tb, int m, int 
 #pragma unroll
     for (int q = 0; q < (N > 0 ? N : 1); ++q) f[q] = 0.0;
 
+    int bypass = 0;
     for (int l0 = 0; l0 < k; l0 += GM_KB) {
         __syncthreads();
         // A tile: rows i0..i0+15, depth l0..l0+31 ; B tile: depth x cols j0..j0+15
@@ -61,7 +62,7 @@ __global__ void __launch_bounds__(GM_THREADS) k_gemm(int ta, int tb, int m, int 
             double p[4], e[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) p[u] = two_prod(As[ty][l + u], Bs[l + u][tx], e[u]);
-            fpe_absorb_prod<N, EE, 4>(f, p, e, sink);
+            fpe_absorb_prod_adaptive<N, EE, 4>(f, p, e, sink, bypass);
         }
     }
     fpe_flush_sink<N>(f, sink);

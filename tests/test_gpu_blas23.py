@@ -143,3 +143,15 @@ def test_exgemm_mfma_path_is_exact(ex, oracle, m, n, k):
                 assert (_bits(c) == _bits(want)).all(), (ta, tb, alpha, beta)
     finally:
         lib.exblas_set_gemm_path(0)
+
+
+def test_standalone_cpp_gemv_gemm_caller(ex):
+    """reference-style C++ program for exgemv / exgemm, linked only against libexblas.so"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["make", "-C", os.path.join(root, "tests", "cpp")], check=True, capture_output=True)
+    for argv in (["512", "384"], ["200", "700"]):
+        r = subprocess.run([os.path.join(root, "tests", "cpp", "test_exgemv_gpu"), *argv], capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0 and "TestPassed; ALL OK!" in r.stdout, (argv, r.stdout[-2000:], r.stderr[-2000:])
