@@ -26,6 +26,8 @@ for step in "$@"; do
           run pmc_fetch timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$R/gpurun_out/pmc_fetch" -- python3 "$R/bench.py" --steps 3 --warmup 1 --prewarm-ms 0 --no-cpu-baseline ;;
     pmc_write) export TMPDIR=/tmp; R=$PWD; rm -rf gpurun_out/pmc_write; \
           run pmc_write timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$R/gpurun_out/pmc_write" -- python3 "$R/bench.py" --steps 3 --warmup 1 --prewarm-ms 0 --no-cpu-baseline ;;
+    pmc_sq) export TMPDIR=/tmp; R=$PWD; rm -rf gpurun_out/pmc_sq; \
+          run pmc_sq timeout -k 10 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$R/gpurun_out/pmc_sq" -- python3 "$R/bench.py" --steps 3 --warmup 1 --prewarm-ms 0 --no-cpu-baseline ;;
     *) echo "unknown step $step" ;;
   esac
 done

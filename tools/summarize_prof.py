@@ -52,6 +52,21 @@ for which, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE"))
     for k, v in acc.items():
         means[k][counter] = sum(v) / len(v)
 
+# SQ pass: per-kernel means of every counter collected (kernel names kept in full, template arguments included)
+f = one("pmc_sq/*/*_counter_collection.csv")
+if f:
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(f)):
+        name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        if "exb::" in name:
+            acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    counters = sorted({c for d in acc.values() for c in d})
+    with open(os.path.join(out, f"{tag}_pmc_sq.csv"), "w") as fh:
+        fh.write("kernel,launches," + ",".join(counters) + "\n")
+        for k, d in sorted(acc.items()):
+            nl = max(len(v) for v in d.values())
+            fh.write(k.replace(",", ";") + f",{nl}," + ",".join(f"{sum(d[c]) / len(d[c]):.6g}" if d.get(c) else "" for c in counters) + "\n")
+
 if means:
     with open(os.path.join(out, f"{tag}_pmc_hbm.csv"), "w") as fh:
         fh.write("kernel,FETCH_SIZE_KB_mean,WRITE_SIZE_KB_mean\n")
