@@ -189,3 +189,50 @@ def test_exsum_segmented(ex, oracle):
         for fpe, ee in FPE_VARIANTS_SUM:
             got = ex.exsum_segmented_dev(dv, do, fpe, ee).cpu().numpy()
             assert (got.view(np.int64) == want.view(np.int64)).all(), (kind, fpe, ee, np.nonzero(got != want)[0][:5])
+
+
+def test_max_size_int_api_limit(ex):
+    """n close to the API's `int` limit (2^31 - 2 elements, 16 GiB): 64-bit indexing, limb headroom (each limb
+    takes < 2^31 adds of < 2^32), known exact answers by construction."""
+    import torch
+    from fractions import Fraction
+    n = (1 << 31) - 2
+    x = ex.gen_dev("cancel", n, 5, 40.0)
+    for fpe, ee in ((8, True), (0, False)):
+        rec = ex.read_record(ex.exsum_dev(x, fpe, ee))
+        assert rec.exact == 1.0 and exact_int_from_digits(rec.digits) == (1 << 1074) + (1 << 1014), (fpe, ee)
+    del x
+    x = ex.gen_dev("naive", n, 1)
+    want = Fraction(1.1) * n                       # exact value of n copies of the double nearest 1.1
+    rec = ex.read_record(ex.exsum_dev(x, 4, True))
+    assert Fraction(exact_int_from_digits(rec.digits), 1 << 1074) == want
+    rec0 = ex.read_record(ex.exsum_dev(x, 0, False))  # every element adds to the same three limbs: worst case headroom
+    assert (rec0.canon == rec.canon).all() and rec0.exact == rec.exact == float(want)
+    torch.cuda.synchronize()
+
+
+def test_hip_graph_capture(ex, oracle):
+    """The device-pointer calls are pure stream-ordered launches: capture 8 ExSUM + ExDOT steps in a graph, replay."""
+    import torch
+    n = (1 << 22) + 2
+    x, y = ex.gen_dev("ill_cond", n, 1, 1e32), ex.gen_dev("lognormal", n, 2, 0.0, 2.0)
+    recs = [ex.new_record_buffer() for _ in range(16)]
+    ex.exsum_dev(x, 8, True, out=recs[0])      # context creation / lazy init outside the capture
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            for i in range(8):
+                ex.exsum_dev(x, 8, True, out=recs[2 * i])
+                ex.exdot_dev(x, y, 8, True, out=recs[2 * i + 1])
+    for r in recs:
+        r.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    hx, hy = oracle.gen("ill_cond", n, 1, 1e32), oracle.gen("lognormal", n, 2, 0.0, 2.0)
+    r0, l0 = oracle.exsum_omp(hx, 8, True, 8, limbs=True)
+    d0, m0 = oracle.exdot_omp(hx, hy, 8, True, 8, limbs=True)
+    for i in range(8):
+        a, b = ex.read_record(recs[2 * i]), ex.read_record(recs[2 * i + 1])
+        assert (a.canon == l0).all() and a.exact == r0 and (b.canon == m0).all() and b.exact == d0
