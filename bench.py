@@ -314,6 +314,11 @@ def main():
             gv["GBs"] = gv["bytes"] * world / (gv["ms"] * 1e-3) / 1e9
             gv["frac_hbm_peak"] = gv["bytes"] / (gv["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
             gm["TFLOPs_2mnk"] = gm["flop_total"] / (gm["ms"] * 1e-3) / 1e12
+            # every product costs slices^2 MFMA-FMAs; f64 MFMA peak 78.6 TFLOP/s per GPU (AMD MI355X datasheet;
+            # equals the fp64 vector rate on CDNA4 -- not listed in MI355X_MICROARCH.md)
+            mf = gm["flop_total"] * gm["slices"] ** 2 / (gm["ms"] * 1e-3) / 1e12
+            gm["roofline"] = {"bound": "mfma", "achieved": mf, "peak": 78.6 * world, "unit": "TFLOP/s",
+                              "frac": mf / (78.6 * world), "traffic": None, "kernel": "k_gemm_mfma"}
             out["exgemv"] = gv
             out["exgemm"] = gm
         if world == 1 and not args.no_cpu_baseline:

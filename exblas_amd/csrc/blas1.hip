@@ -177,8 +177,8 @@ __global__ void __launch_bounds__(BLOCK) k_exsum_strided(const double *__restric
 // ExDOT: TwoProductFMA front-end (ExDOT.Superacc.cl:25-29, :244-253); the rounding error of the
 // product enters the expansion at slot max(N-3,0) like ExDOT.FPE.cl:254
 // ---------------------------------------------------------------------------------------------
-template <int N, bool EE, int COPIES, int U, bool NT, bool PF>
-__global__ void __launch_bounds__(BLOCK) k_exdot(const double *__restrict__ a, const double *__restrict__ b,
+template <int N, bool EE, int COPIES, int U, bool NT, bool PF, int WPS = 1>
+__global__ void __launch_bounds__(BLOCK, WPS) k_exdot(const double *__restrict__ a, const double *__restrict__ b,
                                                  long long n, long long *__restrict__ gacc,
                                                  unsigned *__restrict__ gflags, int ngroups)
 {
@@ -421,11 +421,11 @@ static hipError_t launch_exsum(Ctx &c, const double *a, long long n, long long i
     return hipGetLastError();
 }
 
-template <int N, bool EE, int COPIES, int U, bool NT, bool PF>
+template <int N, bool EE, int COPIES, int U, bool NT, bool PF, int WPS = 1>
 static void run_exdot(Ctx &c, const double *a, const double *b, long long n, hipStream_t st)
 {
     int grid = grid_for(c, n, (long long)BLOCK * 2 * U, c.bpc_dot);
-    hipLaunchKernelGGL((k_exdot<N, EE, COPIES, U, NT, PF>), dim3(grid), dim3(BLOCK), 0, st, a, b, n, c.gacc,
+    hipLaunchKernelGGL((k_exdot<N, EE, COPIES, U, NT, PF, WPS>), dim3(grid), dim3(BLOCK), 0, st, a, b, n, c.gacc,
                        c.gflags, c.ngroups);
 }
 
@@ -444,7 +444,9 @@ static hipError_t launch_exdot(Ctx &c, const double *a, long long inca, const do
             case 4: run_exdot<N, EE, COPIES, 2, false, true>(c, a, b, n, st); break;
             case 5: run_exdot<N, EE, COPIES, 1, true, false>(c, a, b, n, st); break;
             case 6: run_exdot<N, EE, COPIES, 2, true, true>(c, a, b, n, st); break;
-            case 7: run_exdot<N, EE, COPIES, 3, true, false>(c, a, b, n, st); break;
+            case 7: run_exdot<N, EE, COPIES, 3, true, true>(c, a, b, n, st); break;
+            case 8: run_exdot<N, EE, COPIES, 4, true, true, 4>(c, a, b, n, st); break;
+            case 9: run_exdot<N, EE, COPIES, 3, true, true, 5>(c, a, b, n, st); break;
             default: run_exdot<N, EE, COPIES, 4, true, true>(c, a, b, n, st); break;
             }
         } else {

@@ -243,7 +243,7 @@ __global__ void __launch_bounds__(MF_THREADS, WPS) k_gemm_mfma(int ta, int tb, i
 {
     constexpr int G = SA + SB - 1;  // accumulator groups d = p+q, d-2 in [0, G)
     constexpr int D = SA + SB;
-    __shared__ double As[SA][MF_KB][32 * RT + 16];  // [slice][k][row (BM <= 64) + pad]
+    __shared__ double As[SA][MF_KB][32 * RT + 17];  // [slice][k][row + pad]; odd pitch: 16 lanes writing 16 k's of one row hit 16 banks
     __shared__ double Bs[SB][MF_KB][32 * CT + 16];  // [slice][k][col (BN <= 64) + pad]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int BM = 32 * RT;
@@ -253,22 +253,25 @@ __global__ void __launch_bounds__(MF_THREADS, WPS) k_gemm_mfma(int ta, int tb, i
     const int i0 = blockIdx.y * BM, j0 = blockIdx.x * BN;
     const int wr = (wave >> 1) * (16 * RT), wc = (wave & 1) * (16 * CT);
 
-    // global -> register staging: 4 elements of A and 4 of B per thread per k-step
-    // A tile 64 rows x 16 k: thread -> (row = tid/4, kq = (tid%4)*4 .. +3); B tile 16 k x 64 cols: (kk = tid/16, cq = (tid%16)*4 .. +3)
-    const int ar = tid / (MF_KB / AEPT), akq = (tid % (MF_KB / AEPT)) * AEPT;
-    const int bk = tid / (BN / BEPT), bcq = (tid % (BN / BEPT)) * BEPT;
-    const int a_row = i0 + ar;
-    const int ea_r = (a_row < m) ? EA[a_row] : 0;
-    int eb_c[BEPT];
+    // global -> register staging, AEPT elements of A and BEPT of B per thread per k-step.  Sixteen consecutive
+    // lanes take sixteen consecutive k of one row of A (128 contiguous bytes of a row-major A) resp. sixteen
+    // consecutive columns of one k of B (128 contiguous bytes of a row-major B); the u-th element of a thread is 16
+    // rows / columns further on.  Both the global loads and the LDS writes of a 16-lane group are then conflict-free.
+    const int ak = tid & 15, ar0 = tid >> 4;   // A: k = ak, rows ar0 + 16*u
+    const int bk = tid >> 4, bc0 = tid & 15;   // B: k = bk, cols bc0 + 16*u
+    int ea_r[AEPT], eb_c[BEPT];
 #pragma unroll
-    for (int u = 0; u < BEPT; ++u) eb_c[u] = (j0 + bcq + u < n) ? EB[j0 + bcq + u] : 0;
+    for (int u = 0; u < AEPT; ++u) ea_r[u] = (i0 + ar0 + 16 * u < m) ? EA[i0 + ar0 + 16 * u] : 0;
+#pragma unroll
+    for (int u = 0; u < BEPT; ++u) eb_c[u] = (j0 + bc0 + 16 * u < n) ? EB[j0 + bc0 + 16 * u] : 0;
 
     auto load_a = [&](int l0, double (&ra)[AEPT]) {
+        const int gl = l0 + ak;
 #pragma unroll
         for (int u = 0; u < AEPT; ++u) {
-            const int gl = l0 + akq + u;
+            const int gi = i0 + ar0 + 16 * u;
             double v = 0.0;
-            if (a_row < m && gl < k) v = alpha * (ta ? a[(long long)gl * lda + a_row] : a[(long long)a_row * lda + gl]);
+            if (gi < m && gl < k) v = alpha * (ta ? a[(long long)gl * lda + gi] : a[(long long)gi * lda + gl]);
             ra[u] = v;
         }
     };
@@ -276,7 +279,7 @@ __global__ void __launch_bounds__(MF_THREADS, WPS) k_gemm_mfma(int ta, int tb, i
         const int gl = l0 + bk;
 #pragma unroll
         for (int u = 0; u < BEPT; ++u) {
-            const int gj = j0 + bcq + u;
+            const int gj = j0 + bc0 + 16 * u;
             double v = 0.0;
             if (gl < k && gj < n) v = tb ? b[(long long)gj * ldb + gl] : b[(long long)gl * ldb + gj];
             rb[u] = v;
@@ -310,16 +313,16 @@ __global__ void __launch_bounds__(MF_THREADS, WPS) k_gemm_mfma(int ta, int tb, i
 #pragma unroll
             for (int u = 0; u < AEPT; ++u) {
                 double sa[SA];
-                slice<SA>(ra[u], ea_r, sa);
+                slice<SA>(ra[u], ea_r[u], sa);
 #pragma unroll
-                for (int p = 0; p < SA; ++p) As[p][akq + u][ar] = sa[p];
+                for (int p = 0; p < SA; ++p) As[p][ak][ar0 + 16 * u] = sa[p];
             }
 #pragma unroll
             for (int u = 0; u < BEPT; ++u) {
                 double sb[SB];
                 slice<SB>(rb[u], eb_c[u], sb);
 #pragma unroll
-                for (int q = 0; q < SB; ++q) Bs[q][bk][bcq + u] = sb[q];
+                for (int q = 0; q < SB; ++q) Bs[q][bk][bc0 + 16 * u] = sb[q];
             }
             // prefetch the next k-step while this one is contracted
             const int ln = l0 + MF_KB;
