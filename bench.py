@@ -61,17 +61,25 @@ def timed_steps(ex, torch, dist, op, tensors, fpe, ee, steps, warmup, world, rec
 
     side = torch.cuda.Stream() if use_dist else None  # second finalize runs beside the next streaming kernel
 
+    slot_free = {}  # record buffer -> event recorded on the side stream once its second finalize has been issued
+
     def retire(limit):
         while len(pending) > limit:
             work, r = pending.pop(0)
             with torch.cuda.stream(side):
                 work.wait()
                 ex.finalize_dev(r[ex.OUT_DIGITS:ex.OUT_DIGITS + ex.SET_WORDS], out=r)
+                ev_done = torch.cuda.Event()
+                ev_done.record()
+            slot_free[r.data_ptr()] = ev_done
             state["last"] = r
 
     def one_step(e0=None, e1=None):
         r = ring[state["i"] % len(ring)]
         state["i"] += 1
+        ev_free = slot_free.pop(r.data_ptr(), None)
+        if ev_free is not None:
+            torch.cuda.current_stream().wait_event(ev_free)  # the buffer's previous occupant is fully retired
         if e0 is not None:
             e0.record()
         if op == "exsum":

@@ -30,6 +30,7 @@ C_ABI_SYMBOLS = [
     "exblas_exgemv", "exblas_exgemm", "exblas_exsum_record", "exblas_exdot_record",
     "exblas_exsum_accumulate_dev", "exblas_exdot_accumulate_dev", "exblas_finish_dev", "exblas_set_tuning",
     "exblas_set_gemm_path", "exblas_last_gemm_slices", "exblas_exsum_segmented_dev",
+    "exblas_set_accumulator_slot",
 ]
 
 _lib = None
@@ -63,6 +64,7 @@ def load_library():
     L.exblas_hip_version.restype = C.c_char_p
     L.exblas_set_round_mode.argtypes = [i32]
     L.exblas_set_tuning.argtypes = [i32, i32, i32]
+    L.exblas_set_accumulator_slot.argtypes = [i32]
     L.exblas_set_gemm_path.argtypes = [i32]
     L.exblas_set_gemm_path.restype = None
     L.exblas_exsum_dev.argtypes = [vp, i64, i64, i32, i32, vp, vp]
@@ -178,6 +180,11 @@ def exdot_accumulate_dev(x, y, fpe=8, early_exit=True, incx=1, incy=1, n=None):
     _check(load_library().exblas_exdot_accumulate_dev(C.c_void_p(x.data_ptr()), incx, C.c_void_p(y.data_ptr()), incy,
                                                       n, fpe, int(early_exit), _stream_ptr(torch)),
            "exdot_accumulate_dev")
+
+
+def set_accumulator_slot(slot):
+    """Select which of the context's two accumulator sets the next accumulate/finish calls use (pipelining)."""
+    _check(load_library().exblas_set_accumulator_slot(int(slot)), "set_accumulator_slot")
 
 
 def finish_dev(out=None):

@@ -81,10 +81,13 @@ Ctx &ctx(int device)
         if (c.ngroups < 1) c.ngroups = 1;
         c.variant = env_int("EXBLAS_VARIANT", 0);
         c.gemm_path = env_int("EXBLAS_GEMM_PATH", 0);
-        EXB_CHECK(hipMalloc(&c.gacc, sizeof(long long) * NL * c.ngroups));
-        EXB_CHECK(hipMemset(c.gacc, 0, sizeof(long long) * NL * c.ngroups));
-        EXB_CHECK(hipMalloc(&c.gflags, 64));
-        EXB_CHECK(hipMemset(c.gflags, 0, 64));
+        EXB_CHECK(hipMalloc(&c.gacc_all, 2 * sizeof(long long) * NL * c.ngroups));
+        EXB_CHECK(hipMemset(c.gacc_all, 0, 2 * sizeof(long long) * NL * c.ngroups));
+        EXB_CHECK(hipMalloc(&c.gflags_all, 128));
+        EXB_CHECK(hipMemset(c.gflags_all, 0, 128));
+        c.gacc = c.gacc_all;
+        c.gflags = c.gflags_all;
+        c.slot = 0;
         EXB_CHECK(hipMalloc(&c.d_record, sizeof(long long) * OUT_WORDS));
         EXB_CHECK(hipHostMalloc(&c.h_record, sizeof(long long) * OUT_WORDS));
         EXB_CHECK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
@@ -255,16 +258,28 @@ int exblas_set_tuning(int blocks_per_cu, int ngroups, int variant)
     if (blocks_per_cu > 0) c.blocks_per_cu = c.bpc_sum = c.bpc_dot = c.bpc_sa = blocks_per_cu;
     if (ngroups > 0 && ngroups != c.ngroups) {
         EXB_CHECK(hipDeviceSynchronize());
-        EXB_CHECK(hipFree(c.gacc));
+        EXB_CHECK(hipFree(c.gacc_all));
         c.ngroups = ngroups;
-        EXB_CHECK(hipMalloc(&c.gacc, sizeof(long long) * NL * c.ngroups));
-        EXB_CHECK(hipMemset(c.gacc, 0, sizeof(long long) * NL * c.ngroups));
+        EXB_CHECK(hipMalloc(&c.gacc_all, 2 * sizeof(long long) * NL * c.ngroups));
+        EXB_CHECK(hipMemset(c.gacc_all, 0, 2 * sizeof(long long) * NL * c.ngroups));
+        c.gacc = c.gacc_all + (size_t)c.slot * NL * c.ngroups;
         EXB_CHECK(hipDeviceSynchronize());
     }
     if (variant >= 0) c.variant = variant;
     return 0;
 }
 int exblas_get_round_mode(void) { return round_mode(); }
+
+int exblas_set_accumulator_slot(int slot)
+{
+    Ctx &c = ctx(-1);
+    std::lock_guard<std::mutex> lk(c.mu);
+    if (slot < 0 || slot > 1) return (int)hipErrorInvalidValue;
+    c.slot = slot;
+    c.gacc = c.gacc_all + (size_t)slot * NL * c.ngroups;
+    c.gflags = c.gflags_all + 16 * slot;
+    return 0;
+}
 
 int exblas_last_gemm_slices(void) { return ctx(-1).last_gemm_slices; }
 

@@ -21,8 +21,13 @@ struct Ctx {
     int variant = 0;         // tuning variant of the production kernels (exblas_set_tuning)
     int last_gemm_slices = 0;  // 0: the last exgemm ran the scalar kernel; 2..4: MFMA path with that many slices
     int gemm_path = 0;       // 0 auto (MFMA-F64 slices when the data qualifies), 1 scalar only, 2 MFMA for every fpe
-    long long *gacc = nullptr;   // [ngroups][NL] int64, zero between calls
-    unsigned *gflags = nullptr;  // non-finite input flags, zero between calls
+    long long *gacc = nullptr;   // ACTIVE accumulator set: [ngroups][NL] int64, zero between calls
+    unsigned *gflags = nullptr;  // non-finite input flags of the active set, zero between calls
+    // two sets, so that the finalize of step i (side stream) can overlap the streaming kernel of step i+1
+    // (exblas_set_accumulator_slot); single-stream callers never leave slot 0
+    long long *gacc_all = nullptr;
+    unsigned *gflags_all = nullptr;
+    int slot = 0;
     // host-pointer API staging
     hipStream_t stream = nullptr;
     void *stage[3] = {nullptr, nullptr, nullptr};

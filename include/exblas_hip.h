@@ -93,6 +93,11 @@ int exblas_exsum_accumulate_dev(const double *d_a, int64_t n, int64_t inca, int 
 int exblas_exdot_accumulate_dev(const double *d_a, int64_t inca, const double *d_b, int64_t incb,
                                 int64_t n, int fpe, int early_exit, void *stream);
 int exblas_finish_dev(void *stream, int64_t *d_out);
+/* The context owns TWO accumulator sets.  *_accumulate_dev and exblas_finish_dev act on the selected one
+ * (0 by default).  A caller that pipelines independent reductions alternates the slot per reduction and runs
+ * exblas_finish_dev on a second stream (ordered by events), so that the finalize of reduction i overlaps the
+ * streaming kernel of reduction i+1 (bench.py does).  Returns 0, or an error for a slot other than 0 / 1. */
+int exblas_set_accumulator_slot(int slot);
 /* Sum `nsets` digit sets (EXBLAS_SET_WORDS int64 each = words [48,120) of a record, e.g. the
  * all-reduced payloads of several GPUs), carry-propagate once and round: the "single global
  * carry-propagated normalise".  d_out may alias d_digit_sets - EXBLAS_OUT_DIGITS (in-place).
