@@ -236,3 +236,36 @@ def test_hip_graph_capture(ex, oracle):
     for i in range(8):
         a, b = ex.read_record(recs[2 * i]), ex.read_record(recs[2 * i + 1])
         assert (a.canon == l0).all() and a.exact == r0 and (b.canon == m0).all() and b.exact == d0
+
+
+def test_randomized_small_cases(ex, oracle):
+    """300 random (n, offset, stride, distribution, variant) cases incl. zeros, signed zeros, subnormals, huge and
+    tiny magnitudes and exact cancellations -- every case bit-exact against the oracle (limbs and double)."""
+    rng = np.random.default_rng(20261004)
+    specials = np.array([0.0, -0.0, 5e-324, -5e-324, 2.2250738585072014e-308, 1.7976931348623157e308,
+                         -1.7976931348623157e308, 1.0, -1.0, 2.0**-1000, 2.0**1000, 2.0**52, 2.0**53 - 1])
+    for case in range(300):
+        n = int(rng.integers(0, 3000))
+        inca = int(rng.choice([1, 1, 1, 2, 3, 5]))
+        off = int(rng.integers(0, 4))
+        total = off + max(n - 1, 0) * inca + 1 + int(rng.integers(0, 3))
+        spread = int(rng.choice([1, 20, 200, 900]))
+        a = rng.standard_normal(total) * np.exp2(rng.integers(-spread, spread, total).astype(np.float64))
+        k = int(rng.integers(0, max(total // 4, 1)))
+        if k:
+            a[rng.integers(0, total, k)] = rng.choice(specials, k)
+        if total > 8 and rng.random() < 0.5:          # plant exact cancellations
+            half = total // 2
+            a[half:2 * half] = -a[:half][rng.permutation(half)]
+        fpe, ee = FPE_VARIANTS_SUM[int(rng.integers(0, len(FPE_VARIANTS_SUM)))]
+        want, limbs = oracle.exsum(a, 0, inca=inca, offset=off, n=n, limbs=True)
+        rec = ex.exsum_record(n, a, inca, off, fpe, ee)
+        assert (rec.canon == limbs).all() and same_double(rec.exact, want), (case, n, inca, off, fpe, ee)
+        if spread <= 200:                             # dot: keep products inside the exact domain
+            b = rng.standard_normal(total) * np.exp2(rng.integers(-spread, spread, total).astype(np.float64))
+            a2 = np.where(np.abs(a) > 1e250, 1.0, a)
+            a2 = np.where((np.abs(a2) < 1e-250) & (a2 != 0), 1.0, a2)
+            fd, ed = FPE_VARIANTS_DOT[int(rng.integers(0, len(FPE_VARIANTS_DOT)))]
+            wd, ld = oracle.exdot(a2, b, 0, inca=inca, offa=off, incb=inca, offb=off, n=n, limbs=True)
+            rd = ex.exdot_record(n, a2, inca, off, b, inca, off, fd, ed)
+            assert (rd.canon == ld).all() and same_double(rd.exact, wd), (case, n, inca, off, fd, ed)
