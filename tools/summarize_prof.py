@@ -23,8 +23,8 @@ os.makedirs(out, exist_ok=True)
 
 
 def one(pattern):
-    g = glob.glob(os.path.join(ROOT, "gpurun_out", pattern))
-    return g[0] if g else None
+    g = sorted(glob.glob(os.path.join(ROOT, "gpurun_out", pattern)), key=os.path.getmtime)
+    return g[-1] if g else None  # newest: gpurun merges every call's files into the same local directory
 
 
 ks = one("prof/*/*_kernel_stats.csv")
