@@ -250,7 +250,15 @@ __global__ void __launch_bounds__(MF_THREADS, WPS) k_gemm_mfma(int ta, int tb, i
     constexpr int AEPT = BM * MF_KB / MF_THREADS;  // A elements per thread per k-step (4 or 2)
     constexpr int BN = 32 * CT;
     constexpr int BEPT = MF_KB * BN / MF_THREADS;  // B elements per thread per k-step (4 or 2)
-    const int i0 = blockIdx.y * BM, j0 = blockIdx.x * BN;
+    // XCD-aware tile order (speed only): workgroups b and b+8 share an XCD (and its L2), so every XCD gets a
+    // contiguous run of the row-major tile sequence and re-reads its A / B panels from its own L2.
+    const int gx = (n + BN - 1) / BN;
+    int wgid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg / 8, r = nwg % 8, xcd = wgid % 8;
+        wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + wgid / 8;  // bijective for any nwg
+    }
+    const int i0 = (wgid / gx) * BM, j0 = (wgid % gx) * BN;
     const int wr = (wave >> 1) * (16 * RT), wc = (wave & 1) * (16 * CT);
 
     // global -> register staging, AEPT elements of A and BEPT of B per thread per k-step.  Sixteen consecutive
@@ -391,7 +399,7 @@ static void launch_mfma(int ta, int tb, int m, int n, int k, double alpha, const
 {
     constexpr int BM = 32 * RT;
     constexpr int BN = 32 * CT;
-    dim3 grid((n + BN - 1) / BN, (m + BM - 1) / BM);
+    dim3 grid(((n + BN - 1) / BN) * ((m + BM - 1) / BM));
     hipLaunchKernelGGL((k_gemm_mfma<SA, SB, RT, CT, WPS>), grid, dim3(MF_THREADS), 0, st, ta, tb, m, n, k, alpha, a, (long long)lda,
                        b, (long long)ldb, beta, c, (long long)ldc, EA, EB);
 }
