@@ -269,3 +269,22 @@ def test_randomized_small_cases(ex, oracle):
             wd, ld = oracle.exdot(a2, b, 0, inca=inca, offa=off, incb=inca, offb=off, n=n, limbs=True)
             rd = ex.exdot_record(n, a2, inca, off, b, inca, off, fd, ed)
             assert (rd.canon == ld).all() and same_double(rd.exact, wd), (case, n, inca, off, fd, ed)
+
+
+def test_error_behaviour_matches_reference(ex):
+    """fpe < 0: the host-pointer API prints and exit(1)s like cpu:ExSUM.cpp:25-28; the *_dev layer returns an error."""
+    import subprocess
+    import sys
+    import torch
+    x = torch.ones(16, dtype=torch.float64, device="cuda")
+    with pytest.raises(RuntimeError):
+        ex.exsum_dev(x, fpe=-1)
+    with pytest.raises(RuntimeError):
+        ex.exdot_dev(x, x, fpe=-3)
+    code = ("import numpy as np, exblas_amd as ex\n"
+            "ex.exsum(4, np.ones(4), 1, 0, -1)\n"
+            "print('not reached')\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                       cwd=__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
+    assert r.returncode == 1 and "not reached" not in r.stdout
+    assert "Size of floating-point expansion should be a positive number" in r.stderr
