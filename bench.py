@@ -269,11 +269,26 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             ddt, dkms = float(t[0]), float(t[1])
         dach = n * 16 / (dkms * 1e-3) / 1e9
+        # plain (inexact) fp64 dot with the same two-stream access pattern: the box's ceiling for this kernel
+        import ctypes as C
+        lib = ex.load_library()
+        stp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        args2 = (C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), n, 0, stp, C.c_void_p(sink.data_ptr()))
+        for _ in range(3):
+            lib.exblas_stream_read2_dev(*args2)
+        p0_, p1_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        p0_.record()
+        for _ in range(10):
+            lib.exblas_stream_read2_dev(*args2)
+        p1_.record()
+        torch.cuda.synchronize()
+        probe2_gbs = 10 * n * 16 / (p0_.elapsed_time(p1_) * 1e-3) / 1e9
         secondary = {"metric": "ExDOT fp64 Gelem/s", "value": n_total * args.steps / ddt / 1e9, "unit": "Gelem/s",
                      "ms_per_step": ddt / args.steps * 1e3,
                      "roofline": {"bound": "hbm", "achieved": dach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": dach / HBM_PEAK_GBS, "traffic": load_traffic(args.traffic_json, "k_exdot"),
-                                  "kernel": "k_exdot",
+                                  "kernel": "k_exdot", "measured_read_probe_GBs": probe2_gbs,
+                                  "frac_of_probe": dach / probe2_gbs,
                                   "kernel_ms": dkms},
                      "result": ex.read_record(rec2).exact}
         del y

@@ -30,7 +30,7 @@ C_ABI_SYMBOLS = [
     "exblas_exgemv", "exblas_exgemm", "exblas_exsum_record", "exblas_exdot_record",
     "exblas_exsum_accumulate_dev", "exblas_exdot_accumulate_dev", "exblas_finish_dev", "exblas_set_tuning",
     "exblas_set_gemm_path", "exblas_last_gemm_slices", "exblas_exsum_segmented_dev",
-    "exblas_set_accumulator_slot",
+    "exblas_set_accumulator_slot", "exblas_stream_read2_dev",
 ]
 
 _lib = None
@@ -79,6 +79,7 @@ def load_library():
                                     i32, vp]
     L.exblas_gen_dev.argtypes = [i32, C.c_uint64, i64, i64, i64, dbl, dbl, vp, vp]
     L.exblas_stream_read_dev.argtypes = [vp, i64, vp, vp]
+    L.exblas_stream_read2_dev.argtypes = [vp, vp, i64, i32, vp, vp]
     L.exblas_exsum.restype = dbl
     L.exblas_exsum.argtypes = [i32, vp, i32, i32, i32, i32]
     L.exblas_exdot.restype = dbl

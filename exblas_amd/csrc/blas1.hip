@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(BLOCK) k_exsum_strided(const double *__restric
 // ExDOT: TwoProductFMA front-end (ExDOT.Superacc.cl:25-29, :244-253); the rounding error of the
 // product enters the expansion at slot max(N-3,0) like ExDOT.FPE.cl:254
 // ---------------------------------------------------------------------------------------------
-template <int N, bool EE, int COPIES, int U, bool NT, bool PF, int WPS = 1>
+template <int N, bool EE, int COPIES, int U, bool NT, bool PF, int WPS = 1, bool HALVES = false>
 __global__ void __launch_bounds__(BLOCK, WPS) k_exdot(const double *__restrict__ a, const double *__restrict__ b,
                                                  long long n, long long *__restrict__ gacc,
                                                  unsigned *__restrict__ gflags, int ngroups)
@@ -228,22 +228,46 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_exdot(const double *__restrict__
             }
         }
         while (t < ntiles) {
-            double x[2 * U], e[2 * U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                x[2 * u] = two_prod(ra[u].x, rb[u].x, e[2 * u]);
-                x[2 * u + 1] = two_prod(ra[u].y, rb[u].y, e[2 * u + 1]);
-            }
             const long long tn = t + gridDim.x;
-            if (tn < ntiles) {
-                const long long base = tn * TILE + threadIdx.x;
+            if constexpr (HALVES) {
+                // two half-tiles: the registers of a half are re-loaded (next tile) as soon as its products are
+                // formed, so only U products + U errors are live at a time (fewer VGPRs -> more waves per SIMD)
+                constexpr int H = U / 2;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    double x[2 * H], e[2 * H];
+#pragma unroll
+                    for (int u = 0; u < H; ++u) {
+                        x[2 * u] = two_prod(ra[h * H + u].x, rb[h * H + u].x, e[2 * u]);
+                        x[2 * u + 1] = two_prod(ra[h * H + u].y, rb[h * H + u].y, e[2 * u + 1]);
+                    }
+                    if (tn < ntiles) {
+                        const long long base = tn * TILE + threadIdx.x;
+#pragma unroll
+                        for (int u = 0; u < H; ++u) {
+                            ra[h * H + u] = ld2<NT>(va + base + (h * H + u) * BLOCK);
+                            rb[h * H + u] = ld2<NT>(vb + base + (h * H + u) * BLOCK);
+                        }
+                    }
+                    fpe_absorb_prod_adaptive<N, EE, 2 * H>(fpe, x, e, sink, bypass);
+                }
+            } else {
+                double x[2 * U], e[2 * U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    ra[u] = ld2<NT>(va + base + u * BLOCK);
-                    rb[u] = ld2<NT>(vb + base + u * BLOCK);
+                    x[2 * u] = two_prod(ra[u].x, rb[u].x, e[2 * u]);
+                    x[2 * u + 1] = two_prod(ra[u].y, rb[u].y, e[2 * u + 1]);
                 }
+                if (tn < ntiles) {
+                    const long long base = tn * TILE + threadIdx.x;
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        ra[u] = ld2<NT>(va + base + u * BLOCK);
+                        rb[u] = ld2<NT>(vb + base + u * BLOCK);
+                    }
+                }
+                fpe_absorb_prod_adaptive<N, EE, 2 * U>(fpe, x, e, sink, bypass);
             }
-            fpe_absorb_prod_adaptive<N, EE, 2 * U>(fpe, x, e, sink, bypass);
             t = tn;
         }
     }
@@ -421,11 +445,11 @@ static hipError_t launch_exsum(Ctx &c, const double *a, long long n, long long i
     return hipGetLastError();
 }
 
-template <int N, bool EE, int COPIES, int U, bool NT, bool PF, int WPS = 1>
+template <int N, bool EE, int COPIES, int U, bool NT, bool PF, int WPS = 1, bool HALVES = false>
 static void run_exdot(Ctx &c, const double *a, const double *b, long long n, hipStream_t st)
 {
     int grid = grid_for(c, n, (long long)BLOCK * 2 * U, c.bpc_dot);
-    hipLaunchKernelGGL((k_exdot<N, EE, COPIES, U, NT, PF, WPS>), dim3(grid), dim3(BLOCK), 0, st, a, b, n, c.gacc,
+    hipLaunchKernelGGL((k_exdot<N, EE, COPIES, U, NT, PF, WPS, HALVES>), dim3(grid), dim3(BLOCK), 0, st, a, b, n, c.gacc,
                        c.gflags, c.ngroups);
 }
 
@@ -445,8 +469,8 @@ static hipError_t launch_exdot(Ctx &c, const double *a, long long inca, const do
             case 5: run_exdot<N, EE, COPIES, 1, true, false>(c, a, b, n, st); break;
             case 6: run_exdot<N, EE, COPIES, 2, true, true>(c, a, b, n, st); break;
             case 7: run_exdot<N, EE, COPIES, 3, true, true>(c, a, b, n, st); break;
-            case 8: run_exdot<N, EE, COPIES, 4, true, true, 4>(c, a, b, n, st); break;
-            case 9: run_exdot<N, EE, COPIES, 3, true, true, 5>(c, a, b, n, st); break;
+            case 8: run_exdot<N, EE, COPIES, 4, true, true, 1, true>(c, a, b, n, st); break;
+            case 9: run_exdot<N, EE, COPIES, 8, true, true, 1, true>(c, a, b, n, st); break;
             default: run_exdot<N, EE, COPIES, 4, true, true>(c, a, b, n, st); break;
             }
         } else {

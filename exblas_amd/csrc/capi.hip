@@ -225,6 +225,31 @@ __global__ void __launch_bounds__(256) k_stream_read(const double *a, long long 
     if (s0 + s1 == 0x1.23456789abcdep-333) *sink = s0;  // keeps the loads alive, never true in practice
 }
 
+// plain (inexact) two-stream dot: read-bandwidth probe for the ExDOT access pattern
+__global__ void __launch_bounds__(256) k_stream_read2(const double *a, const double *b, long long n, double *sink)
+{
+    const d2_t *va = (const d2_t *)a, *vb = (const d2_t *)b;
+    const long long nv = n >> 1;
+    double s0 = 0, s1 = 0;
+    constexpr int U = 4;
+    const long long tile = 256ll * U, ntiles = nv / tile;
+    for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const long long base = t * tile + threadIdx.x;
+        d2_t r[U], q[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            r[u] = __builtin_nontemporal_load(va + base + u * 256);
+            q[u] = __builtin_nontemporal_load(vb + base + u * 256);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            s0 += r[u].x * q[u].x;
+            s1 += r[u].y * q[u].y;
+        }
+    }
+    if (s0 + s1 == 0x1.23456789abcdep-333) *sink = s0;
+}
+
 }  // namespace exb
 
 using namespace exb;
@@ -401,6 +426,16 @@ int exblas_stream_read_dev(const double *d_a, int64_t n, void *stream, double *d
     Ctx &c = ctx(-1);
     long long blocks = (long long)c.num_cu * c.blocks_per_cu;
     hipLaunchKernelGGL(k_stream_read, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_a, (long long)n,
+                       d_sink);
+    return (int)hipGetLastError();
+}
+
+int exblas_stream_read2_dev(const double *d_a, const double *d_b, int64_t n, int blocks_per_cu, void *stream,
+                            double *d_sink)
+{
+    Ctx &c = ctx(-1);
+    long long blocks = (long long)c.num_cu * (blocks_per_cu > 0 ? blocks_per_cu : c.bpc_dot);
+    hipLaunchKernelGGL(k_stream_read2, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_a, d_b, (long long)n,
                        d_sink);
     return (int)hipGetLastError();
 }

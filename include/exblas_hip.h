@@ -120,6 +120,9 @@ int exblas_gen_dev(int kind, uint64_t seed, int64_t first, int64_t count, int64_
 /* Plain streaming read (sum of doubles, not exact): measures the box's achievable read bandwidth,
  * the second roofline denominator of BASELINE.md section 3. */
 int exblas_stream_read_dev(const double *d_a, int64_t n, void *stream, double *d_sink);
+/* the same for the two-stream (ExDOT) access pattern: plain fp64 dot, blocks_per_cu <= 0 uses the ExDOT geometry */
+int exblas_stream_read2_dev(const double *d_a, const double *d_b, int64_t n, int blocks_per_cu, void *stream,
+                            double *d_sink);
 
 /* ---- (1) host-pointer layer (reference semantics; copies H2D per call like gpu:ExSUM.cpp:126) -- */
 double exblas_exsum(int Ng, const double *ag, int inca, int offset, int fpe, int early_exit);
