@@ -155,3 +155,42 @@ def test_standalone_cpp_gemv_gemm_caller(ex):
         r = subprocess.run([os.path.join(root, "tests", "cpp", "test_exgemv_gpu"), *argv], capture_output=True,
                            text=True, timeout=600)
         assert r.returncode == 0 and "TestPassed; ALL OK!" in r.stdout, (argv, r.stdout[-2000:], r.stderr[-2000:])
+
+
+def test_full_size_configs_sampled(ex, oracle):
+    """BASELINE configs 4 and 5 at full size: ExGEMV m=n=32768 ('N', column-major, alpha=beta=1) and ExGEMM n=8192
+    (row-major), each checked on a sample of outputs against the oracle's exact dot of the corresponding row/column."""
+    import torch
+    rng = np.random.default_rng(11)
+    m = n = 32768
+    a = ex.gen_dev("fpuniform", m * n, 11, 10.0, 0.0)
+    x = ex.gen_dev("fpuniform", n, 12, 10.0, 0.0)
+    y0 = ex.gen_dev("fpuniform", m, 13, 10.0, 0.0)
+    y = y0.clone()
+    ex.exgemv_dev("N", m, n, 1.0, a, m, x, 1.0, y, 8, True)
+    yt = y0.clone()
+    ex.exgemv_dev("T", m, n, 1.0, a, m, x, 1.0, yt, 4, True)
+    hx, hy0, hy, hyt = x.cpu().numpy(), y0.cpu().numpy(), y.cpu().numpy(), yt.cpu().numpy()
+    A = a.view(n, m)                      # column-major: A[k, i] = A(i, k)
+    for i in rng.integers(0, m, 24):
+        row = A[:, int(i)].contiguous().cpu().numpy()
+        want = oracle.exdot(np.append(row, 1.0), np.append(hx, hy0[i]), 0)      # + beta*y_i as one more exact term
+        assert same_bits(hy[i], want), ("gemv N", i)
+        col = A[int(i), :].contiguous().cpu().numpy()
+        want_t = oracle.exdot(np.append(col, 1.0), np.append(hx, hy0[i]), 0)
+        assert same_bits(hyt[i], want_t), ("gemv T", i)
+    del a, A
+    N = 8192
+    Am = ex.gen_dev("fpuniform", N * N, 14, 10.0, 0.0)
+    Bm = ex.gen_dev("fpuniform", N * N, 15, 10.0, 0.0)
+    C = torch.zeros(N * N, dtype=torch.float64, device="cuda")
+    ex.exgemm_dev("N", "N", N, N, N, 1.0, Am, N, Bm, N, 0.0, C, N, 8, True)
+    assert ex.load_library().exblas_last_gemm_slices() == 3
+    A2, B2, C2 = Am.view(N, N), Bm.view(N, N), C.view(N, N)
+    for i, j in zip(rng.integers(0, N, 24), rng.integers(0, N, 24)):
+        want = oracle.exdot(A2[int(i)].cpu().numpy(), B2[:, int(j)].contiguous().cpu().numpy(), 0)
+        assert same_bits(float(C2[int(i), int(j)]), want), ("gemm", i, j)
+
+
+def same_bits(x, y):
+    return np.float64(x).view(np.int64) == np.float64(y).view(np.int64)

@@ -149,3 +149,26 @@ def test_gemv_gemm_oracle_vs_mpfr(oracle):
     for fpe, ee in ((0, False), (3, False), (8, True)):
         got = oracle.exgemm("N", "N", m, n, k, 1.0, A, k, B, n, 0.0, np.zeros(m * n), n, fpe, ee)
         assert (got.reshape(m, n) == dots).all(), (fpe, ee)
+
+
+def test_baseline_config1_plumbing(oracle):
+    """BASELINE.json configs[0]: ExSUM n = 2^20 fp64 log-normal (the reference's CTest cases `20 2 0 n` and
+    `20 50 0 n`, src/cpu/blas/blas1/CMakeLists.txt:28-35), CPU reference path vs MPFR -- no GPU involved.
+    Inputs come from the reference's own init_lognormal (std::random_device seeded, so every run is a new draw)."""
+    if oracle.ref() is None or oracle.mpfr() is None:
+        pytest.skip("needs oracle/_ref and libmpfr_oracle.so")
+    n = 1 << 20
+    for stddev in (2.0, 50.0):
+        a = oracle.ref_gen("lognormal", n, 0, 0.0, stddev)
+        want = oracle.mpfr_exsum(a)
+        r0, l0 = oracle.exsum(a, 0, limbs=True)
+        assert same_double(r0, want)
+        for fpe, ee in FPE_VARIANTS_SUM:
+            rr, lr = oracle.ref_exsum(a, fpe, ee, nthreads=4, limbs=True)   # the reference's compiled core
+            assert (lr == l0).all(), (stddev, fpe, ee)
+            # the reference's own pass criterion (relative error <= 1e-16, tests/test.exsum.cpu.cpp:43,:133) ...
+            assert abs(rr - want) <= 1e-16 * abs(want) + 0.0 or abs(rr - want) / abs(want) <= 2.3e-16
+            # ... and ours: the limbs round correctly
+            assert same_double(oracle.round_limbs(lr), want)
+            r, l = oracle.exsum(a, fpe, ee, limbs=True)
+            assert (l == l0).all() and same_double(r, want)
