@@ -317,44 +317,43 @@ __global__ void __launch_bounds__(BLOCK) k_exdot_strided(const double *__restric
 // finalize: sum `nsets` limb vectors, ONE carry propagation, canonical limbs, rounding.
 // zero_sets: the input is the context's group accumulators -> leave them zeroed for the next call.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(128) k_finalize(long long *sets, int nsets, int set_stride, unsigned *gflags,
-                                                  unsigned flags_or, int zero_sets, long long *out)
+__global__ void __launch_bounds__(64) k_finalize(long long *sets, int nsets, int set_stride, unsigned *gflags,
+                                                 unsigned flags_or, int zero_sets, long long *out)
 {
-    __shared__ FinishShared fs;
-    __shared__ unsigned s_fl;
-    const int t = threadIdx.x;
-    if (t == 0) {
-        unsigned flags = flags_or;
-        if (gflags) {
-            flags |= *gflags;
-            if (zero_sets) *gflags = 0;
-        }
-        if (set_stride >= SET_WORDS)  // record-style sets carry their own flag indicators
-            for (int g = 0; g < nsets; ++g)
-                for (int k = 0; k < 3; ++k)
-                    if (sets[(size_t)g * set_stride + NL + k] != 0) flags |= (1u << k);
-        s_fl = flags;
+    // one wavefront: lane l owns limb l and (l < 4) limb 64+l
+    const int lane = threadIdx.x;
+    unsigned flags = flags_or;
+    if (gflags) flags |= *gflags;
+    if (set_stride >= SET_WORDS) {  // record-style sets carry their own flag indicators
+        for (int g = 0; g < nsets; ++g)
+            for (int k = 0; k < 3; ++k)
+                if (sets[(size_t)g * set_stride + NL + k] != 0) flags |= (1u << k);
     }
-    if (t < NL) {
-        // all loads of a batch are issued before the first use (the words were last touched by other
-        // CUs' atomics, so each load is a full memory round trip: 32 dependent ones cost ~20 us)
-        long long s = 0;
-        for (int g0 = 0; g0 < nsets; g0 += 16) {
-            long long tmp[16];
+    // all loads of a batch are issued before the first use (the words were last touched by other CUs' atomics,
+    // so each load is a full memory round trip: 32 dependent ones cost ~20 us)
+    long long v0 = 0, v1 = 0;
+    for (int g0 = 0; g0 < nsets; g0 += 16) {
+        long long t0[16], t1[16];
 #pragma unroll
-            for (int k = 0; k < 16; ++k)
-                tmp[k] = (g0 + k < nsets) ? __builtin_nontemporal_load(&sets[(size_t)(g0 + k) * set_stride + t]) : 0;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) s += tmp[k];
+        for (int k = 0; k < 16; ++k) {
+            const bool ok = g0 + k < nsets;
+            const long long *p = sets + (size_t)(ok ? g0 + k : 0) * set_stride;
+            t0[k] = ok ? __builtin_nontemporal_load(p + lane) : 0;
+            t1[k] = (ok && lane < NL - 64) ? __builtin_nontemporal_load(p + 64 + lane) : 0;
         }
-        fs.v[t] = s;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            v0 += t0[k];
+            v1 += t1[k];
+        }
     }
     if (zero_sets) {
-        __syncthreads();
-        for (int i = t; i < nsets * set_stride; i += blockDim.x) sets[i] = 0;
+        for (int i = lane; i < nsets * set_stride; i += 64) sets[i] = 0;
+        if (lane == 0 && gflags) *gflags = 0;
     }
-    __syncthreads();  // every input word is read before the first output word is written (out may alias sets)
-    finish_record_block<128>(fs, s_fl, out);
+    // every input word has been read (into registers) before the first output word is written: out may alias sets
+    const WaveFinish r = finish_wave(v0, v1, flags);
+    write_record_wave(r, flags, out);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -368,17 +367,17 @@ __global__ void __launch_bounds__(BLOCK) k_exsum_segmented(const double *__restr
                                                            const long long *__restrict__ offsets, long long nseg,
                                                            int round_mode, double *__restrict__ out)
 {
-    __shared__ FinishShared fs[WAVES];
+    __shared__ long long acc[WAVES][NL];
     __shared__ unsigned fl[WAVES];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const long long seg = (long long)blockIdx.x * WAVES + w;
     const bool valid = seg < nseg;
-    for (int t = lane; t < NL; t += 64) fs[w].v[t] = 0;
+    for (int t = lane; t < NL; t += 64) acc[w][t] = 0;
     if (lane == 0) fl[w] = 0;
     __syncthreads();
     if (valid) {
         unsigned flags = 0;
-        LdsSink<1> sink{fs[w].v, flags};
+        LdsSink<1> sink{acc[w], flags};
         double fpe[N > 0 ? N : 1];
 #pragma unroll
         for (int i = 0; i < (N > 0 ? N : 1); ++i) fpe[i] = 0.0;
@@ -393,8 +392,8 @@ __global__ void __launch_bounds__(BLOCK) k_exsum_segmented(const double *__restr
         if (flags) atomicOr(&fl[w], flags);
     }
     __syncthreads();
-    finish_core<64>(fs[w], lane, fl[w]);
-    if (valid && lane == 0) out[seg] = round_mode ? fs[w].rf : __longlong_as_double((long long)fs[w].ex);
+    const WaveFinish r = finish_wave(acc[w][lane], lane < NL - 64 ? acc[w][64 + lane] : 0, fl[w]);
+    if (valid && lane == 0) out[seg] = round_mode ? r.rf : __longlong_as_double((long long)r.ex);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -486,13 +485,13 @@ static hipError_t launch_exdot(Ctx &c, const double *a, long long inca, const do
 
 hipError_t finalize_groups(Ctx &c, hipStream_t st, long long *d_out)
 {
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(128), 0, st, c.gacc, c.ngroups, NL, c.gflags, 0u, 1, d_out);
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, st, c.gacc, c.ngroups, NL, c.gflags, 0u, 1, d_out);
     return hipGetLastError();
 }
 
 hipError_t finalize_sets(const long long *d_sets, int nsets, unsigned flags_or, hipStream_t st, long long *d_out)
 {
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(128), 0, st, const_cast<long long *>(d_sets), nsets, SET_WORDS,
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, st, const_cast<long long *>(d_sets), nsets, SET_WORDS,
                        (unsigned *)nullptr, flags_or, 0, d_out);
     return hipGetLastError();
 }

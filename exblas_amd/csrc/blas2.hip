@@ -147,17 +147,17 @@ __global__ void __launch_bounds__(GV_BLOCK) k_gemv_finish(int rows, int nvals, c
                                                           const long long *__restrict__ ws, double beta,
                                                           double *__restrict__ y, long long incy, int round_mode)
 {
-    __shared__ FinishShared fs[GV_WAVES];
+    __shared__ long long acc[GV_WAVES][NL];
     __shared__ unsigned fl[GV_WAVES];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const long long row = (long long)blockIdx.x * GV_WAVES + w;
     const bool valid = row < rows;
-    for (int t = lane; t < NL; t += 64) fs[w].v[t] = 0;
+    for (int t = lane; t < NL; t += 64) acc[w][t] = 0;
     if (lane == 0) fl[w] = 0;
     __syncthreads();
     if (valid) {
         unsigned flags = 0;
-        LdsSink<1> sink{fs[w].v, flags};
+        LdsSink<1> sink{acc[w], flags};
         const double *pr = part + (size_t)row * nvals;
         for (int i = lane; i < nvals; i += 64) {
             const double v = pr[i];
@@ -176,14 +176,14 @@ __global__ void __launch_bounds__(GV_BLOCK) k_gemv_finish(int rows, int nvals, c
         const long long *g = ws + row * SET_WORDS;
         for (int t = lane; t < NL; t += 64) {
             const long long v = g[t];
-            if (v) atomicAdd((unsigned long long *)&fs[w].v[t], (unsigned long long)v);
+            if (v) atomicAdd((unsigned long long *)&acc[w][t], (unsigned long long)v);
         }
         if (lane < 3 && g[NL + lane] != 0) flags |= 1u << lane;
         if (flags) atomicOr(&fl[w], flags);
     }
     __syncthreads();
-    finish_core<64>(fs[w], lane, fl[w]);
-    if (valid && lane == 0) y[row * incy] = round_mode ? fs[w].rf : __longlong_as_double((long long)fs[w].ex);
+    const WaveFinish r = finish_wave(acc[w][lane], lane < NL - 64 ? acc[w][64 + lane] : 0, fl[w]);
+    if (valid && lane == 0) y[row * incy] = round_mode ? r.rf : __longlong_as_double((long long)r.ex);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -195,7 +195,7 @@ __global__ void __launch_bounds__(GV_BLOCK) k_gemvT(int m, double alpha, const d
                                                     double *__restrict__ y, long long incy, int round_mode)
 {
     __shared__ long long s_acc[GV_WAVES * NL * COPIES];
-    __shared__ FinishShared fs;
+    __shared__ long long merged[NL];
     __shared__ unsigned s_flags;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < GV_WAVES * NL * COPIES; i += GV_BLOCK) s_acc[i] = 0;
@@ -257,11 +257,13 @@ __global__ void __launch_bounds__(GV_BLOCK) k_gemvT(int m, double alpha, const d
         for (int w = 0; w < GV_WAVES; ++w)
 #pragma unroll
             for (int c = 0; c < COPIES; ++c) sum += s_acc[(w * NL + l) * COPIES + c];
-        fs.v[l] = sum;
+        merged[l] = sum;
     }
     __syncthreads();
-    finish_core<GV_BLOCK>(fs, tid, s_flags);
-    if (tid == 0) y[j * incy] = round_mode ? fs.rf : __longlong_as_double((long long)fs.ex);
+    if (wave == 0) {  // one wavefront carries, cuts and rounds (shuffles + ballots only)
+        const WaveFinish r = finish_wave(merged[lane], lane < NL - 64 ? merged[64 + lane] : 0, s_flags);
+        if (lane == 0) y[j * incy] = round_mode ? r.rf : __longlong_as_double((long long)r.ex);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

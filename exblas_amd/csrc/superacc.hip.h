@@ -267,130 +267,110 @@ __device__ inline void finish_record(long long *v, unsigned flags, long long *ou
 }
 
 // ---------------------------------------------------------------------------------------------
-// The same final step done cooperatively: GROUP consecutive threads of a workgroup (64 = one wave,
-// or the whole block) work on one FinishShared; several groups of a block may each finish their own
-// accumulator at the same time, so every barrier below is block-wide and block-uniform (ALL threads
-// of the block must call).  Carry propagation runs as lane-parallel passes (a carry moves one digit
-// per pass; sums of < 2^31 chunks settle in 2-3 passes, the loop runs until no digit of any group is
-// out of range), leading-digit / sticky searches are LDS min/max reductions, canonical limbs are cut
-// one per thread.  Must (and is tested to) match the single-thread version above bit for bit.
+// The final step inside ONE wavefront, registers only: lane l holds limb l (v0) and, for l < 4, limb 64+l (v1).
+// Carries travel one lane per pass with __shfl_up (wave-wide vote ends the loop), the leading / lowest non-zero
+// digits come from __ballot masks, canonical limbs are cut with per-lane __shfl gathers.  No LDS, no barrier.
+// All 64 lanes must call it.  Same bits as the single-thread finish_record above (the scalar ExGEMM kernel still
+// uses that one; the parity tests run both against the oracle).
 // ---------------------------------------------------------------------------------------------
-struct FinishShared {
-    long long v[NL];        // in: raw limb sums; out: normalised digits (top limb signed)
-    long long canon[CANON];
-    unsigned mag[NL];
-    int z, top, ci, cz;
-    unsigned long long ex;  // out: bits of the correctly rounded double
-    double rf;              // out: reference-compatible rounding
+struct WaveFinish {
+    unsigned long long ex;  // bits of the correctly rounded double (uniform)
+    double rf;              // reference-compatible rounding (uniform)
+    long long canon;        // lane j < 41: canonical limb j
+    long long d0, d1;       // normalised digits: limb lane, and limb 64+lane for lane < 4
 };
 
-template <int GROUP>
-__device__ inline void finish_core(FinishShared &s, const int lane /* 0..GROUP-1 */, const unsigned flags)
+__device__ inline WaveFinish finish_wave(long long v0, long long v1, const unsigned flags)
 {
-    if (lane == 0) { s.z = NL; s.top = -1; s.ci = -1; s.cz = CANON; }
-    // ---- carry propagation, all digits at once per pass ----
-    constexpr int PER = (NL + GROUP - 1) / GROUP;
+    const int lane = (int)(threadIdx.x & 63u);
+    constexpr int HI = NL - 64;  // limbs kept in the second register (4); limb NL-1 is the signed top limb
+    if (lane >= HI) v1 = 0;
+    // ---- carry propagation: one lane per pass ----
     for (int pass = 0; pass < 2 * NL; ++pass) {
-        long long lo[PER], cin[PER];
-#pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            const int t = lane + k * GROUP;
-            lo[k] = cin[k] = 0;
-            if (t < NL) {
-                lo[k] = (t < NL - 1) ? (s.v[t] & 0xffffffffll) : s.v[t];
-                cin[k] = (t > 0) ? (s.v[t - 1] >> 32) : 0;  // arithmetic: signed carry of the digit below
-            }
-        }
-        __syncthreads();
-        bool pending = false;
-#pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            const int t = lane + k * GROUP;
-            if (t < NL) {
-                const long long nv = lo[k] + cin[k];
-                s.v[t] = nv;
-                pending |= (t < NL - 1) && ((nv >> 32) != 0);
-            }
-        }
-        if (!__syncthreads_or(pending)) break;
+        const long long c0 = v0 >> 32, lo0 = v0 & 0xffffffffll;
+        const bool emits1 = lane < HI - 1;
+        const long long c1 = emits1 ? (v1 >> 32) : 0, lo1 = emits1 ? (v1 & 0xffffffffll) : v1;
+        long long in0 = __shfl_up(c0, 1), in1 = __shfl_up(c1, 1);
+        const long long c63 = __shfl(c0, 63);
+        if (lane == 0) { in0 = 0; in1 = c63; }
+        v0 = lo0 + in0;
+        v1 = (lane < HI) ? lo1 + in1 : 0;
+        const bool pending = ((v0 >> 32) != 0) || (emits1 && (v1 >> 32) != 0);
+        if (!__any(pending)) break;
     }
-    // ---- magnitude digits, leading / lowest non-zero digit ----
-    const bool neg = s.v[NL - 1] < 0;
-    for (int t = lane; t < NL; t += GROUP)
-        if ((unsigned)s.v[t]) atomicMin(&s.z, t);
-    __syncthreads();
+    WaveFinish r;
+    r.d0 = v0;
+    r.d1 = v1;
+    const long long top = __shfl(v1, HI - 1);
+    const bool neg = top < 0;
+    const unsigned d0 = (unsigned)v0, d1 = (unsigned)v1;
+    // ---- magnitude digits ----
+    const unsigned long long nz0 = __ballot(d0 != 0), nz1 = __ballot(lane < HI && d1 != 0);
+    const int z = nz0 ? __builtin_ctzll(nz0) : (nz1 ? 64 + __builtin_ctzll(nz1) : NL);
+    const int i1 = 64 + lane;
+    const unsigned m0 = !neg ? d0 : (lane < z ? 0u : (lane == z ? (0u - d0) : ~d0));
+    const unsigned m1 = (lane >= HI) ? 0u : (!neg ? d1 : (i1 < z ? 0u : (i1 == z ? (0u - d1) : ~d1)));
+    const unsigned long long mz0 = __ballot(m0 != 0), mz1 = __ballot(m1 != 0);
+    const int tp = mz1 ? 64 + (63 - __builtin_clzll(mz1)) : (mz0 ? 63 - __builtin_clzll(mz0) : -1);
+    auto mag = [&](int i) -> unsigned {  // i uniform
+        const unsigned a = __shfl(m0, i & 63), b = __shfl(m1, (i - 64) & 63);
+        return i < 0 ? 0u : (i < 64 ? a : b);
+    };
+    unsigned long long ex = 0ull;
+    const unsigned long long sign = neg ? 0x8000000000000000ull : 0ull;
     {
-        const int z = s.z;
-        for (int t = lane; t < NL; t += GROUP) {
-            const unsigned d = (unsigned)s.v[t];
-            const unsigned m = !neg ? d : (t < z ? 0u : (t == z ? (0u - d) : ~d));
-            s.mag[t] = m;
-            if (m) atomicMax(&s.top, t);
-        }
-    }
-    // ---- canonical limbs, one per thread ----
-    for (int t = lane; t < CANON; t += GROUP) {
-        long long cj;
-        if (t < CANON - 1) {
-            cj = digits_field52(s.v, CANON_DIGITS * t - 18);
-        } else {
-            const int o = CANON_DIGITS * (CANON - 1) - 18;
-            const int q = o >> 5, r = o & 31;
-            auto dig = [&](int i) -> unsigned long long {
-                if (i >= NL - 1) {
-                    const long long top = s.v[NL - 1];
-                    const int k = i - (NL - 1);
-                    if (k == 0) return (unsigned long long)(unsigned)top;
-                    if (k == 1) return (unsigned long long)(unsigned)(top >> 32);
-                    return (top < 0) ? 0xffffffffull : 0ull;
-                }
-                return (unsigned long long)(unsigned)s.v[i];
-            };
-            const unsigned long long lo = dig(q) | (dig(q + 1) << 32);
-            const unsigned long long hi = dig(q + 2) | (dig(q + 3) << 32);
-            cj = (long long)(r ? ((lo >> r) | (hi << (64 - r))) : lo);
-        }
-        s.canon[t] = cj;
-        const long long mask = (1ll << CANON_DIGITS) - 1;
-        // leading word of Superaccumulator::Round: zeros are skipped, and for a negative value
-        // all-ones words too (the signed top word of a negative value is never zero)
-        if (neg ? ((cj & mask) != mask) : (cj != 0)) atomicMax(&s.ci, t);
-        if (cj != 0) atomicMin(&s.cz, t);
-    }
-    __syncthreads();
-    // ---- the two roundings (lane 0) ----
-    if (lane == 0) {
-        unsigned long long ex = 0ull;
-        const int tp = s.top;
-        const unsigned long long sign = neg ? 0x8000000000000000ull : 0ull;
+        const unsigned mt = mag(tp < 0 ? 0 : tp), ma = mag(tp - 1), mb = mag(tp - 2), q0 = mag(0), q1 = mag(1);
         if (tp >= 0) {
-            const unsigned mt = s.mag[tp];
-            const int lz = __builtin_clz(mt);
+            const int lz = __builtin_clz(mt | 1u);  // mt != 0 here; the OR only keeps the builtin defined
             const int msb = 32 * tp + 31 - lz;
             if (msb <= 52) {
-                ex = sign | (((unsigned long long)(tp >= 1 ? s.mag[1] : 0u) << 32) | s.mag[0]);
+                ex = sign | (((unsigned long long)(tp >= 1 ? q1 : 0u) << 32) | q0);
             } else {
-                const unsigned d1 = (tp >= 1) ? s.mag[tp - 1] : 0u, d2 = (tp >= 2) ? s.mag[tp - 2] : 0u;
-                unsigned long long w = ((unsigned long long)mt << 32) | d1;
-                unsigned rest = d2;
+                unsigned long long w = ((unsigned long long)mt << 32) | ma;
+                unsigned rest = mb;
                 if (lz) {
-                    w = (w << lz) | (unsigned long long)(d2 >> (32 - lz));
-                    rest = d2 << lz;
+                    w = (w << lz) | (unsigned long long)(mb >> (32 - lz));
+                    rest = mb << lz;
                 }
-                // digits below tp-2: non-zero iff the lowest non-zero digit lies there
-                const bool sticky = (w & 0x3ffull) != 0 || rest != 0 || s.z < tp - 2;
+                const bool sticky = (w & 0x3ffull) != 0 || rest != 0 || z < tp - 2;
                 unsigned long long bits = ((unsigned long long)(msb - 52) << 52) + (w >> 11);
                 if (((w >> 10) & 1ull) && (sticky || (bits & 1ull))) bits += 1;
                 if ((bits >> 52) >= 0x7ffull) bits = 0x7ff0000000000000ull;
                 ex = sign | bits;
             }
         }
-        // reference-compatible rounding (superaccumulator.cpp:80-134), leading word index s.ci
-        double rf = 0.0;
-        const int i = s.ci;
+    }
+    // ---- canonical limbs: lane j cuts bits [52j-18, 52j+34) of the two's-complement digit string ----
+    auto digit = [&](int i) -> unsigned long long {  // i per lane; digits beyond the top limb are its sign extension
+        const unsigned a = __shfl(d0, i & 63), b = __shfl(d1, (i - 64) & 63);
+        const int k = i - (NL - 1);
+        unsigned v = (i < 64) ? a : b;
+        if (k == 0) v = (unsigned)top;
+        if (k == 1) v = (unsigned)(top >> 32);
+        if (k >= 2) v = neg ? 0xffffffffu : 0u;
+        return i < 0 ? 0ull : (unsigned long long)v;
+    };
+    {
+        const int j = lane < CANON ? lane : 0;
+        const int o = CANON_DIGITS * j - 18;
+        const int q = o >> 5, sh = o & 31;
+        const unsigned long long lo = digit(q) | (digit(q + 1) << 32), hi = digit(q + 2) | (digit(q + 3) << 32);
+        const unsigned long long win = sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;
+        r.canon = (j == CANON - 1) ? (long long)win : (long long)(win & ((1ull << CANON_DIGITS) - 1));
+    }
+    // ---- reference-compatible rounding (superaccumulator.cpp:80-134) ----
+    double rf = 0.0;
+    {
+        const long long mask = (1ll << CANON_DIGITS) - 1;
+        const long long cj = r.canon;
+        const bool in = lane < CANON;
+        const unsigned long long lead = __ballot(in && (neg ? ((cj & mask) != mask) : (cj != 0)));
+        const unsigned long long nzc = __ballot(in && cj != 0);
+        const int i = lead ? 63 - __builtin_clzll(lead) : -1;
+        const int cz = nzc ? __builtin_ctzll(nzc) : CANON;
+        const long long ci = __shfl(cj, i < 0 ? 0 : i), cl = __shfl(cj, i < 1 ? 0 : i - 1);
         if (i >= 0) {
-            const long long mask = (1ll << CANON_DIGITS) - 1;
-            long long hiword = neg ? mask - s.canon[i] : s.canon[i];
+            long long hiword = neg ? mask - ci : ci;
             const double rounded = (double)hiword;
             double hi = ldexp(rounded, (i - CANON_FWORDS) * CANON_DIGITS);
             if (i == 0) {
@@ -398,9 +378,8 @@ __device__ inline void finish_core(FinishShared &s, const int lane /* 0..GROUP-1
             } else {
                 hiword -= __double2ll_rn(rounded);
                 const double mid = ldexp((double)hiword, (i - CANON_FWORDS) * CANON_DIGITS);
-                // sticky over words 0..i-2: for a negative value every term (2^52 - word) is non-zero
-                const bool sticky = neg ? (i >= 2) : (s.cz < i - 1);
-                long long loword = neg ? (1ll << CANON_DIGITS) - s.canon[i - 1] : s.canon[i - 1];
+                const bool sticky = neg ? (i >= 2) : (cz < i - 1);
+                long long loword = neg ? (1ll << CANON_DIGITS) - cl : cl;
                 loword |= (long long)sticky;
                 double lo = ldexp((double)loword, (i - 1 - CANON_FWORDS) * CANON_DIGITS);
                 if (mid != 0) {
@@ -412,27 +391,24 @@ __device__ inline void finish_core(FinishShared &s, const int lane /* 0..GROUP-1
                 rf = neg ? -hi : hi;
             }
         }
-        if (flags) {
-            const bool nan = (flags & FLAG_NAN) || ((flags & FLAG_PINF) && (flags & FLAG_NINF));
-            ex = nan ? 0x7ff8000000000000ull
-                     : ((flags & FLAG_NINF) ? 0xfff0000000000000ull : 0x7ff0000000000000ull);
-            rf = __longlong_as_double((long long)ex);
-        }
-        s.ex = ex;
-        s.rf = rf;
     }
-    __syncthreads();
+    if (flags) {
+        const bool nan = (flags & FLAG_NAN) || ((flags & FLAG_PINF) && (flags & FLAG_NINF));
+        ex = nan ? 0x7ff8000000000000ull : ((flags & FLAG_NINF) ? 0xfff0000000000000ull : 0x7ff0000000000000ull);
+        rf = __longlong_as_double((long long)ex);
+    }
+    r.ex = ex;
+    r.rf = rf;
+    return r;
 }
 
-// whole-block version writing the full record (blockDim.x threads cooperate, >= 64)
-template <int GROUP>
-__device__ inline void finish_record_block(FinishShared &s, unsigned flags, long long *out)
+// one wave writes the full record
+__device__ inline void write_record_wave(const WaveFinish &r, unsigned flags, long long *out)
 {
-    const int t = threadIdx.x;
-    finish_core<GROUP>(s, t, flags);
-    if (t == 0) {
-        out[OUT_EXACT] = (long long)s.ex;
-        out[OUT_REFMODE] = __double_as_longlong(s.rf);
+    const int lane = (int)(threadIdx.x & 63u);
+    if (lane == 0) {
+        out[OUT_EXACT] = (long long)r.ex;
+        out[OUT_REFMODE] = __double_as_longlong(r.rf);
         out[OUT_FLAGS] = (long long)flags;
         out[3] = 0;
         out[OUT_FLAGCNT + 0] = (flags & FLAG_PINF) ? 1 : 0;
@@ -440,8 +416,9 @@ __device__ inline void finish_record_block(FinishShared &s, unsigned flags, long
         out[OUT_FLAGCNT + 2] = (flags & FLAG_NAN) ? 1 : 0;
         out[OUT_FLAGCNT + 3] = 0;
     }
-    for (int j = t; j < CANON; j += GROUP) out[OUT_CANON + j] = s.canon[j];
-    for (int j = t; j < NL; j += GROUP) out[OUT_DIGITS + j] = s.v[j];
+    if (lane < CANON) out[OUT_CANON + lane] = r.canon;
+    out[OUT_DIGITS + lane] = r.d0;
+    if (lane < NL - 64) out[OUT_DIGITS + 64 + lane] = r.d1;
 }
 
 }  // namespace exb
