@@ -43,7 +43,6 @@ __device__ __forceinline__ void static_for(F &&f)
 constexpr int MF_BETA = 21;
 constexpr int MF_KP = 512;    // k-block over which MFMA partial sums stay exact
 constexpr int MF_KB = 16;  // workgroup tile: BM = 32*RT rows x BN = 32*CT columns (RT x CT MFMA tiles of 16x16 per wave)
-constexpr int MF_LDP = 80;    // padded leading dimension of the [k][row] slice planes
 constexpr int MF_THREADS = 256;
 
 // info words written by the scan kernels
