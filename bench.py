@@ -130,11 +130,29 @@ def timed_steps(ex, torch, dist, op, tensors, fpe, ee, steps, warmup, world, rec
     return dt, kms
 
 
+def host_cores():
+    """CPU threads this process may actually run: the affinity mask, capped by the cgroup CPU quota."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            cores = max(1, min(cores, int(-(-int(quota) // int(period)))))
+    except Exception:  # noqa: BLE001  (cgroup v1 or no cgroup: keep the affinity count)
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p_ = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                cores = max(1, min(cores, -(-q // p_)))
+        except Exception:  # noqa: BLE001
+            pass
+    return cores
+
+
 def cpu_baseline(op, host_arrays, fpe, ee, limbs_gpu):
     """Time the CPU path on this box's host cores, on the same vector(s); returns the JSON object."""
     import numpy as np
     from oracle import pyoracle as O
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = host_cores()
     n = host_arrays[0].size
     use_ref = op == "exsum" and O.ref() is not None
     os.environ.setdefault("OMP_NUM_THREADS", str(cores))
