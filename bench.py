@@ -149,35 +149,47 @@ def host_cores():
 
 
 def cpu_baseline(op, host_arrays, fpe, ee, limbs_gpu):
-    """Time the CPU path on this box's host cores, on the same vector(s); returns the JSON object."""
+    """Time the CPU path on this box's host cores, on the same vector(s); returns the JSON object.
+
+    The cgroup of a GPU box grants fewer CPUs (cpu.max) than the affinity mask shows, but short runs may burst
+    beyond the quota; the thread count is therefore swept (quota, 2x, 4x, ... up to the physical cores) and the
+    FASTEST configuration is reported, with its thread count -- the most favourable number for the CPU."""
     import numpy as np
     from oracle import pyoracle as O
-    cores = host_cores()
+    quota = host_cores()
+    affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else quota
     n = host_arrays[0].size
     use_ref = op == "exsum" and O.ref() is not None
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
-    best = None
-    reps = 0
-    t_start = time.perf_counter()
-    limbs = None
-    while reps < 5 and (time.perf_counter() - t_start) < 25.0:
-        t0 = time.perf_counter()
+    counts = sorted({max(1, min(affinity, c)) for c in (quota, 2 * quota, 4 * quota, affinity // 2)})
+
+    def run(nt):
         if use_ref:
-            _, limbs = O.ref_exsum(host_arrays[0], fpe, ee, nthreads=cores, limbs=True)
-        elif op == "exsum":
-            _, limbs = O.exsum_omp(host_arrays[0], fpe, ee, cores, limbs=True)
-        else:
-            _, limbs = O.exdot_omp(host_arrays[0], host_arrays[1], fpe, ee, cores, limbs=True)
-        dt = time.perf_counter() - t0
-        best = dt if best is None else min(best, dt)
-        reps += 1
+            return O.ref_exsum(host_arrays[0], fpe, ee, nthreads=nt, limbs=True)[1]
+        if op == "exsum":
+            return O.exsum_omp(host_arrays[0], fpe, ee, nt, limbs=True)[1]
+        return O.exdot_omp(host_arrays[0], host_arrays[1], fpe, ee, nt, limbs=True)[1]
+
+    best, best_nt, limbs, tried = None, quota, None, {}
+    t_start = time.perf_counter()
+    for nt in counts:
+        for _ in range(3):
+            if time.perf_counter() - t_start > 25.0 and best is not None:
+                break
+            t0 = time.perf_counter()
+            limbs = run(nt)
+            dt = time.perf_counter() - t0
+            tried[nt] = min(dt, tried.get(nt, dt))
+            if best is None or dt < best:
+                best, best_nt = dt, nt
     ok = bool((np.asarray(limbs) == np.asarray(limbs_gpu)).all())
     impl = ("reference FPExpansionVect+Superaccumulator (oracle/_ref, -O1 -mavx2 -mfma) under our OpenMP slice driver"
             if use_ref else "oracle/exblas_oracle.c OpenMP port")
+    sweep = ", ".join(f"{k} thr: {n / v / 1e9:.2f}" for k, v in sorted(tried.items()))
     return {
-        "value": n / best / 1e9, "unit": "Gelem/s", "cores": cores,
+        "value": n / best / 1e9, "unit": "Gelem/s", "cores": best_nt,
         "kind": "reference" if use_ref else "port",
-        "sample": f"full workload, n={n}, {impl}, fpe={fpe} early_exit={ee}, best of {reps}",
+        "sample": f"full workload, n={n}, {impl}, fpe={fpe} early_exit={ee}; cgroup cpu quota {quota}, affinity "
+                  f"{affinity}; best of 3 per thread count, Gelem/s by threads: {sweep}",
         "seconds": best,
     }, ok
 
