@@ -331,7 +331,10 @@ __global__ void __launch_bounds__(64) k_finalize(long long *sets, int nsets, int
     }
     // all loads of a batch are issued before the first use (the words were last touched by other CUs' atomics,
     // so each load is a full memory round trip: 32 dependent ones cost ~20 us)
-    long long v0 = 0, v1 = 0;
+    // The low 32 bits and the (signed) high parts of the sets are summed separately and the high parts enter one
+    // limb up, so this sum cannot overflow however many adds the sets hold (each set alone stays below 2^63 as long
+    // as it received fewer than 2^31 adds: with 32 group accumulators that is 2^36 values per reduction).
+    long long lo0 = 0, hi0 = 0, lo1 = 0, hi1 = 0;
     for (int g0 = 0; g0 < nsets; g0 += 16) {
         long long t0[16], t1[16];
 #pragma unroll
@@ -343,10 +346,20 @@ __global__ void __launch_bounds__(64) k_finalize(long long *sets, int nsets, int
         }
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-            v0 += t0[k];
-            v1 += t1[k];
+            lo0 += t0[k] & 0xffffffffll;
+            hi0 += t0[k] >> 32;
+            if (lane == NL - 65) {  // the top limb is never split
+                lo1 += t1[k];
+            } else {
+                lo1 += t1[k] & 0xffffffffll;
+                hi1 += t1[k] >> 32;
+            }
         }
     }
+    long long in0 = __shfl_up(hi0, 1), in1 = __shfl_up(hi1, 1);
+    const long long h63 = __shfl(hi0, 63);
+    if (lane == 0) { in0 = 0; in1 = h63; }
+    const long long v0 = lo0 + in0, v1 = (lane < NL - 64) ? lo1 + in1 : 0;
     if (zero_sets) {
         for (int i = lane; i < nsets * set_stride; i += 64) sets[i] = 0;
         if (lane == 0 && gflags) *gflags = 0;

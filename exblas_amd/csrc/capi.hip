@@ -317,7 +317,7 @@ void exblas_set_gemm_path(int mode)
 
 int exblas_exsum_accumulate_dev(const double *d_a, int64_t n, int64_t inca, int fpe, int early_exit, void *stream)
 {
-    if (fpe < 0) return (int)hipErrorInvalidValue;
+    if (fpe < 0 || n > 0x7fffffffll) return (int)hipErrorInvalidValue;
     Ctx &c = ctx(-1);
     std::lock_guard<std::mutex> lk(c.mu);
     bool ok = true;
@@ -328,7 +328,7 @@ int exblas_exsum_accumulate_dev(const double *d_a, int64_t n, int64_t inca, int 
 int exblas_exdot_accumulate_dev(const double *d_a, int64_t inca, const double *d_b, int64_t incb, int64_t n, int fpe,
                                 int early_exit, void *stream)
 {
-    if (fpe < 0) return (int)hipErrorInvalidValue;
+    if (fpe < 0 || n > 0x7fffffffll) return (int)hipErrorInvalidValue;
     Ctx &c = ctx(-1);
     std::lock_guard<std::mutex> lk(c.mu);
     bool ok = true;

@@ -87,7 +87,10 @@ int exblas_exsum_segmented_dev(const double *d_values, const int64_t *d_offsets,
 /* The two phases of the calls above, separately: *_accumulate_dev launches only the streaming kernel
  * and adds its result into the context's (zero-initialised) accumulators, so several arrays can be
  * folded into ONE exact sum; exblas_finish_dev carry-propagates, rounds, writes the record and
- * leaves the accumulators zero again.  bench.py brackets the streaming kernel with events this way. */
+ * leaves the accumulators zero again.  bench.py brackets the streaming kernel with events this way.
+ * Capacity: one reduction (everything between two exblas_finish_dev calls) may hold up to 2^36 values (each of the
+ * 32 group accumulators takes 2^31 adds; the finalize sums them carry-safely); a single call takes n < 2^31 like
+ * the reference API's `int Ng` -- larger n is rejected with an error. */
 int exblas_exsum_accumulate_dev(const double *d_a, int64_t n, int64_t inca, int fpe, int early_exit,
                                 void *stream);
 int exblas_exdot_accumulate_dev(const double *d_a, int64_t inca, const double *d_b, int64_t incb,

@@ -208,6 +208,12 @@ def test_max_size_int_api_limit(ex):
     assert Fraction(exact_int_from_digits(rec.digits), 1 << 1074) == want
     rec0 = ex.read_record(ex.exsum_dev(x, 0, False))  # every element adds to the same three limbs: worst case headroom
     assert (rec0.canon == rec.canon).all() and rec0.exact == rec.exact == float(want)
+    # three arrays folded into ONE reduction: 3 * (2^31 - 2) values, more than one int64 limb could take if the
+    # finalize summed the group accumulators naively (each add moves a limb by up to 2^32 - 1)
+    for _ in range(3):
+        ex.exsum_accumulate_dev(x, 0, False)
+    rec3 = ex.read_record(ex.finish_dev())
+    assert Fraction(exact_int_from_digits(rec3.digits), 1 << 1074) == 3 * want
     torch.cuda.synchronize()
 
 
