@@ -3,9 +3,12 @@
 // Replaces the reference's OpenCL kernels ExSUM/ExSUMComplete (src/gpu/blas/blas1/ExSUM.Superacc.cl:211-356,
 // ExSUM.FPE.cl:230-388, ExSUM.FPE.EX.{4,6,8}.cl) and ExDOT/ExDOTComplete (ExDOT.Superacc.cl:217-359,
 // ExDOT.FPE.cl:201-345) -- behaviour only; the structure is ours:
-//   * every lane streams 16-byte (double2) coalesced, non-temporal loads, U of them in flight per tile;
+//   * every lane streams 16-byte (double2) coalesced, non-temporal loads, U of them in flight per tile, and the
+//     next tile is already on its way into a second register set while the current one is absorbed;
 //   * a register-resident floating-point expansion of NFPE doubles absorbs the elements with Knuth
-//     TwoSum; the early-exit test is one wave-uniform branch per level per *tile* (not per element);
+//     TwoSum; the early-exit test is one wave-uniform branch per level per *tile* (not per element); a tile
+//     whose residues outlive all levels switches the wave to the direct path for the next 63 tiles
+//     (fpe_absorb_adaptive), a tile with |x| >= 2^1000 / Inf / NaN takes the range guard (fpe_guard);
 //   * what survives the expansion is split by integer shifts and added with ds_add_u64 to a
 //     per-wavefront superaccumulator in LDS (COPIES columns per wave, limb-major, see superacc.hip.h);
 //   * block epilogue: merge the columns, add the non-zero limbs to one of NGROUPS global accumulators
