@@ -12,6 +12,7 @@
  */
 #include "exblas_oracle.h"
 
+#include <float.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -84,6 +85,10 @@ static inline void orc_accumulate_word(orc_superacc *sa, int64_t x, int i)
 void orc_sa_accumulate(orc_superacc *sa, double x)
 {
     if (x == 0) return;
+    /* Inf/NaN: the reference's loop below never terminates on them and walks off the limb array
+     * (superaccumulator.hpp:173-194 has no check).  The oracle drops the value instead of faulting; tests
+     * that feed non-finite data state IEEE's expected answer themselves. */
+    if (!(fabs(x) <= DBL_MAX)) return;
     int e = orc_exponent(x);
     int exp_word = e / ORC_DIGITS; /* C truncation, as the reference */
     int iup = exp_word + ORC_FWORDS;

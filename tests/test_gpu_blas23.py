@@ -194,3 +194,42 @@ def test_full_size_configs_sampled(ex, oracle):
 
 def same_bits(x, y):
     return np.float64(x).view(np.int64) == np.float64(y).view(np.int64)
+
+
+def test_exgemm_mfma_fallbacks(ex, oracle):
+    """Inputs the MFMA slice path must refuse (it then runs the scalar kernel): subnormals, Inf/NaN, huge exponents,
+    an all-zero operand; plus rows/columns of zeros and signed zeros inside the fast path.  Always the oracle's bits."""
+    lib = ex.load_library()
+    m, n, k = 48, 40, 96
+    base_a = oracle.gen("fpuniform_signed", m * k, 71, 8, 4)
+    base_b = oracle.gen("fpuniform_signed", k * n, 72, 8, 4)
+    c0 = np.zeros(m * n)
+
+    def run(a, b, want_fast):
+        # the oracle (like the reference) has no defined behaviour on Inf/NaN: take its exact result on the finite
+        # part and IEEE's answer (numpy's matmul class: +-Inf or NaN) for the entries a non-finite value reaches
+        fa, fb = np.where(np.isfinite(a), a, 0.0), np.where(np.isfinite(b), b, 0.0)
+        want = oracle.exgemm("N", "N", m, n, k, 1.0, fa, k, fb, n, 0.0, c0, n, 0)
+        with np.errstate(all="ignore"):
+            ieee = (a.reshape(m, k) @ b.reshape(k, n)).reshape(-1)
+        if not (np.isfinite(a).all() and np.isfinite(b).all()):
+            want = np.where(np.isfinite(ieee), want, ieee)
+        c = c0.copy()
+        ex.exgemm("N", "N", m, n, k, 1.0, a, k, b, n, 0.0, c, n, 8, True)
+        used = lib.exblas_last_gemm_slices()
+        assert want_fast is None or (used >= 2) == want_fast, used
+        ok = (_bits(c) == _bits(want)) | (np.isnan(c) & np.isnan(want))
+        assert ok.all(), np.nonzero(~ok)[0][:5]
+
+    a = base_a.copy(); a[5] = 5e-324
+    run(a, base_b, False)                                  # subnormal entry
+    a = base_a.copy(); a[7] = np.inf
+    run(a, base_b, False)                                  # Inf
+    b = base_b.copy(); b[3] = np.nan
+    run(base_a, b, False)                                  # NaN
+    run(base_a * 2.0**500, base_b, False)                  # exponents outside +-400
+    run(base_a, np.zeros(k * n), None)                     # all-zero operand: either path, exact zeros
+    run(np.zeros(m * k), np.zeros(k * n), False)           # nothing but zeros: scalar path
+    a = base_a.copy().reshape(m, k); a[3, :] = 0.0; a[10, ::2] = -0.0
+    b = base_b.copy().reshape(k, n); b[:, 7] = 0.0
+    run(a.reshape(-1), b.reshape(-1), True)                # zero row / zero column / signed zeros: fast path
