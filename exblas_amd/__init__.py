@@ -30,7 +30,7 @@ C_ABI_SYMBOLS = [
     "exblas_exgemv", "exblas_exgemm", "exblas_exsum_record", "exblas_exdot_record",
     "exblas_exsum_accumulate_dev", "exblas_exdot_accumulate_dev", "exblas_finish_dev", "exblas_set_tuning",
     "exblas_set_gemm_path", "exblas_last_gemm_slices", "exblas_exsum_segmented_dev",
-    "exblas_set_accumulator_slot", "exblas_stream_read2_dev",
+    "exblas_set_accumulator_slot", "exblas_stream_read2_dev", "exblas_extrsv_dev", "exblas_extrsv",
 ]
 
 _lib = None
@@ -77,6 +77,8 @@ def load_library():
     L.exblas_exgemv_dev.argtypes = [C.c_char, i32, i32, dbl, vp, i32, vp, i32, dbl, vp, i32, i32, i32, vp]
     L.exblas_exgemm_dev.argtypes = [C.c_char, C.c_char, i32, i32, i32, dbl, vp, i32, vp, i32, dbl, vp, i32, i32,
                                     i32, vp]
+    L.exblas_extrsv_dev.argtypes = [C.c_char, C.c_char, C.c_char, i32, vp, i32, vp, i32, i32, i32, vp]
+    L.exblas_extrsv.argtypes = [C.c_char, C.c_char, C.c_char, i32, vp, i32, i32, vp, i32, i32, i32, i32]
     L.exblas_gen_dev.argtypes = [i32, C.c_uint64, i64, i64, i64, dbl, dbl, vp, vp]
     L.exblas_stream_read_dev.argtypes = [vp, i64, vp, vp]
     L.exblas_stream_read2_dev.argtypes = [vp, vp, i64, i32, vp, vp]
@@ -230,6 +232,17 @@ def exgemv_dev(trans, m, n, alpha, a, lda, x, beta, y, fpe=0, early_exit=False, 
     return y
 
 
+def extrsv_dev(uplo, trans, diag, n, a, lda, x, fpe=0, early_exit=False, incx=1):
+    """x := A^-1 x (or A^-T x) in place on device tensors; returns 0, or -1 for the unsupported fpe >= 9."""
+    torch = _require_gpu()
+    rc = load_library().exblas_extrsv_dev(uplo.encode(), trans.encode(), diag.encode(), n, C.c_void_p(a.data_ptr()),
+                                          lda, C.c_void_p(x.data_ptr()), incx, fpe, int(early_exit),
+                                          _stream_ptr(torch))
+    if rc != -1:
+        _check(rc, "extrsv_dev")
+    return rc
+
+
 def exgemm_dev(transa, transb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, fpe=0, early_exit=False):
     torch = _require_gpu()
     _check(load_library().exblas_exgemm_dev(transa.encode(), transb.encode(), m, n, k, alpha,
@@ -319,6 +332,16 @@ def exgemv(transa, m, n, alpha, a, lda, offseta, x, incx, offsetx, beta, y, incy
     return load_library().exblas_exgemv(transa.encode(), m, n, alpha, C.c_void_p(a_.ctypes.data), lda, offseta,
                                         C.c_void_p(x_.ctypes.data), incx, offsetx, beta, C.c_void_p(y.ctypes.data),
                                         incy, offsety, fpe, int(bool(early_exit)))
+
+
+def extrsv(uplo, transa, diag, n, a, lda, offseta, x, incx, offsetx, fpe, early_exit=False):
+    """int extrsv(...) -- include/blas2.hpp:57; x (numpy float64) holds b on entry and the solution on return."""
+    _require_gpu()
+    a_ = _host(a)
+    assert isinstance(x, np.ndarray) and x.dtype == np.float64 and x.flags.c_contiguous
+    return load_library().exblas_extrsv(uplo.encode(), transa.encode(), diag.encode(), n, C.c_void_p(a_.ctypes.data),
+                                        lda, offseta, C.c_void_p(x.ctypes.data), incx, offsetx, fpe,
+                                        int(bool(early_exit)))
 
 
 def exgemm(transa, transb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, fpe, early_exit=False):

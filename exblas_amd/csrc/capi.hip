@@ -382,6 +382,18 @@ int exblas_exgemv_dev(char transa, int m, int n, double alpha, const double *d_a
                                 round_mode(), (hipStream_t)stream);
 }
 
+int exblas_extrsv_dev(char uplo, char transa, char diag, int n, const double *d_a, int lda, double *d_x, int incx,
+                      int fpe, int early_exit, void *stream)
+{
+    if (fpe < 0) return (int)hipErrorInvalidValue;
+    if (fpe >= 9) return EXBLAS_UNSUPPORTED;
+    if (n > 0 && (lda < n || incx <= 0)) return (int)hipErrorInvalidValue;
+    Ctx &c = ctx(-1);
+    std::lock_guard<std::mutex> lk(c.mu);
+    return (int)extrsv_dispatch(c, uplo, transa, diag, n, d_a, lda, d_x, incx, fpe, early_exit, round_mode(),
+                                (hipStream_t)stream);
+}
+
 int exblas_exgemm_dev(char transa, char transb, int m, int n, int k, double alpha, const double *d_a, int lda,
                       const double *d_b, int ldb, double beta, double *d_c, int ldc, int fpe, int early_exit,
                       void *stream)
@@ -562,6 +574,35 @@ int exblas_exgemv(char transa, int m, int n, double alpha, const double *a, int 
     return 0;
 }
 
+int exblas_extrsv(char uplo, char transa, char diag, int n, const double *a, int lda, int offseta, double *x,
+                  int incx, int offsetx, int fpe, int early_exit)
+{
+    check_fpe(fpe);
+    if (fpe >= 9) {
+        fprintf(stderr, "exblas(hip): extrsv fpe = %d selects an iterative-refinement kernel the reference does not "
+                        "ship (ExTRSV.cpp:91-120); nothing done\n", fpe);
+        return -1;
+    }
+    if (n <= 0) return 0;
+    Ctx &c = ctx(-1);
+    std::lock_guard<std::mutex> api_lock(c.api_mu);
+    double *d_a, *d_x;
+    const size_t abytes = ((size_t)lda * (size_t)(n - 1) + (size_t)n) * sizeof(double);  // n columns of lda
+    const size_t xspan = (size_t)(n - 1) * (size_t)incx + 1;
+    {
+        std::lock_guard<std::mutex> lk(c.mu);
+        d_a = (double *)stage_buf(c, 0, abytes);
+        d_x = (double *)stage_buf(c, 1, xspan * sizeof(double));
+        EXB_CHECK(hipMemcpyAsync(d_a, a + offseta, abytes, hipMemcpyHostToDevice, c.stream));
+        EXB_CHECK(hipMemcpyAsync(d_x, x + offsetx, xspan * sizeof(double), hipMemcpyHostToDevice, c.stream));
+    }
+    int rc = exblas_extrsv_dev(uplo, transa, diag, n, d_a, lda, d_x, incx, fpe, early_exit, c.stream);
+    if (rc) die("exblas_extrsv_dev", (hipError_t)rc, __FILE__, __LINE__);
+    EXB_CHECK(hipMemcpyAsync(x + offsetx, d_x, xspan * sizeof(double), hipMemcpyDeviceToHost, c.stream));
+    EXB_CHECK(hipStreamSynchronize(c.stream));
+    return 0;
+}
+
 int exblas_exgemm(char transa, char transb, int m, int n, int k, double alpha, const double *a, int lda,
                   const double *b, int ldb, double beta, double *cm, int ldc, int fpe, int early_exit)
 {
@@ -621,11 +662,7 @@ int exgemv(const char transa, const int m, const int n, const double alpha, doub
 int extrsv(const char uplo, const char transa, const char diag, const int n, double *a, const int lda,
            const int offseta, double *x, const int incx, const int offsetx, const int fpe, const bool early_exit)
 {
-    // declared for link compatibility (blas2.hpp:57); the triangular solve is outside the reduction hot path
-    (void)uplo; (void)transa; (void)diag; (void)n; (void)a; (void)lda; (void)offseta; (void)x; (void)incx;
-    (void)offsetx; (void)fpe; (void)early_exit;
-    fprintf(stderr, "exblas(hip): extrsv is not implemented by this backend\n");
-    return -1;
+    return exblas_extrsv(uplo, transa, diag, n, a, lda, offseta, x, incx, offsetx, fpe, early_exit ? 1 : 0);
 }
 
 int exgemm(char transa, char transb, int m, int n, int k, double alpha, double *a, int lda, double *b, int ldb,

@@ -70,6 +70,10 @@ hipError_t exgemm_dispatch(Ctx &c, char transa, char transb, int m, int n, int k
                            int lda, const double *b, int ldb, double beta, double *cmat, int ldc, int fpe,
                            int early_exit, int round_mode, hipStream_t st);
 
+// trsv.hip
+hipError_t extrsv_dispatch(Ctx &c, char uplo, char transa, char diag, int n, const double *a, int lda, double *x,
+                           int incx, int fpe, int early_exit, int round_mode, hipStream_t st);
+
 bool exgemm_try_mfma(Ctx &c, char transa, char transb, int m, int n, int k, double alpha, const double *a, int lda,
                      const double *b, int ldb, double beta, double *cmat, int ldc, hipStream_t st, hipError_t *err);
 

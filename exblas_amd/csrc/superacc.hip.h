@@ -280,23 +280,43 @@ struct WaveFinish {
     long long d0, d1;       // normalised digits: limb lane, and limb 64+lane for lane < 4
 };
 
+template <bool FULL = true>
 __device__ inline WaveFinish finish_wave(long long v0, long long v1, const unsigned flags)
 {
     const int lane = (int)(threadIdx.x & 63u);
     constexpr int HI = NL - 64;  // limbs kept in the second register (4); limb NL-1 is the signed top limb
     if (lane >= HI) v1 = 0;
-    // ---- carry propagation: one lane per pass ----
-    for (int pass = 0; pass < 2 * NL; ++pass) {
-        const long long c0 = v0 >> 32, lo0 = v0 & 0xffffffffll;
-        const bool emits1 = lane < HI - 1;
-        const long long c1 = emits1 ? (v1 >> 32) : 0, lo1 = emits1 ? (v1 & 0xffffffffll) : v1;
+    // ---- carry propagation: one lane per pass, confined to the limbs that hold something ----
+    // Limbs 0..hi (hi = highest non-zero limb) are cut to 32 bits; limb hi+1 only collects what leaves limb hi
+    // (|.| < 2^32) and is sign-extended to the top afterwards.  Without this a negative total would need one pass
+    // per empty limb above it for the borrow to reach the top limb.
+    const unsigned long long nzA = __ballot(v0 != 0), nzB = __ballot(v1 != 0);
+    const int hi = nzB ? 64 + (63 - __builtin_clzll(nzB)) : (nzA ? 63 - __builtin_clzll(nzA) : -1);
+    const bool split0 = lane <= hi;
+    const bool split1 = (64 + lane <= hi) && (lane < HI - 1);  // the top limb is never cut
+    for (int pass = 0; pass < 2 * NL && hi >= 0; ++pass) {
+        const long long c0 = split0 ? (v0 >> 32) : 0, lo0 = split0 ? (v0 & 0xffffffffll) : v0;
+        const long long c1 = split1 ? (v1 >> 32) : 0, lo1 = split1 ? (v1 & 0xffffffffll) : v1;
         long long in0 = __shfl_up(c0, 1), in1 = __shfl_up(c1, 1);
         const long long c63 = __shfl(c0, 63);
         if (lane == 0) { in0 = 0; in1 = c63; }
         v0 = lo0 + in0;
         v1 = (lane < HI) ? lo1 + in1 : 0;
-        const bool pending = ((v0 >> 32) != 0) || (emits1 && (v1 >> 32) != 0);
+        const bool pending = (split0 && (v0 >> 32) != 0) || (split1 && (v1 >> 32) != 0);
         if (!__any(pending)) break;
+    }
+    if (hi >= 0 && hi + 1 < NL - 1) {  // sign-extend limb hi+1 through the empty limbs up to the top one
+        const int e = hi + 1;
+        const long long s0 = __shfl(v0, e & 63), s1 = __shfl(v1, (e - 64) & 63);
+        const long long sv = e < 64 ? s0 : s1;
+        const long long fill = sv < 0 ? 0xffffffffll : 0ll;
+        if (lane == e) v0 = sv & 0xffffffffll;
+        if (lane > e) v0 = fill;
+        if (lane < HI) {
+            const int i1 = 64 + lane;
+            if (i1 == e) v1 = sv & 0xffffffffll;
+            if (i1 > e) v1 = (i1 == NL - 1) ? (sv < 0 ? -1ll : 0ll) : fill;
+        }
     }
     WaveFinish r;
     r.d0 = v0;
@@ -340,6 +360,9 @@ __device__ inline WaveFinish finish_wave(long long v0, long long v1, const unsig
             }
         }
     }
+    double rf = 0.0;
+    r.canon = 0;
+    if constexpr (FULL) {
     // ---- canonical limbs: lane j cuts bits [52j-18, 52j+34) of the two's-complement digit string ----
     auto digit = [&](int i) -> unsigned long long {  // i per lane; digits beyond the top limb are its sign extension
         const unsigned a = __shfl(d0, i & 63), b = __shfl(d1, (i - 64) & 63);
@@ -359,7 +382,6 @@ __device__ inline WaveFinish finish_wave(long long v0, long long v1, const unsig
         r.canon = (j == CANON - 1) ? (long long)win : (long long)(win & ((1ull << CANON_DIGITS) - 1));
     }
     // ---- reference-compatible rounding (superaccumulator.cpp:80-134) ----
-    double rf = 0.0;
     {
         const long long mask = (1ll << CANON_DIGITS) - 1;
         const long long cj = r.canon;
@@ -391,6 +413,7 @@ __device__ inline WaveFinish finish_wave(long long v0, long long v1, const unsig
                 rf = neg ? -hi : hi;
             }
         }
+    }
     }
     if (flags) {
         const bool nan = (flags & FLAG_NAN) || ((flags & FLAG_PINF) && (flags & FLAG_NINF));

@@ -1,0 +1,270 @@
+// trsv.hip -- ExTRSV: reproducible triangular solve  A x = b  /  A**T x = b  (x holds b on entry), column-major A.
+//
+//     x_i = fl( Round( b_i - sum_j A(i,j) * x_j ) / A(i,i) )        j before i in the substitution order
+//
+// with the sum exact (TwoProd into expansions + integer superaccumulator) and Round the superaccumulator rounding:
+// the arithmetic of the reference kernels (src/gpu/blas/blas2/ExTRSV.lnn.Superacc.cl:254-348 lower,
+// ExTRSV.unn.Superacc.cl:262-355 upper; FPE variants ExTRSV.{lnn,unn}.FPE*.cl; dispatch ExTRSV.cpp:70-123).
+// Unlike the reference kernels, which ignore them (isunit = 0 at lnn.Superacc.cl:272; no transposed kernel exists),
+// transa, diag, incx and lda are honoured.
+//
+// Shape of the computation on MI355X.  The n rounded divisions form one dependency chain -- x_i needs x_{i-1} --
+// so the solve is LATENCY bound, not HBM bound: the n^2/2 matrix elements (0.56 ms of HBM time at n = 32768) are
+// consumed far faster than the chain advances.  The design therefore keeps everything off the chain that can be:
+//   * one workgroup per block-row of 64 rows (lane = row, 4 waves split the 64 columns of a tile); block-rows are
+//     handed out by an atomic ticket in dependency order, so a workgroup only ever waits for workgroups that
+//     already run (no deadlock when there are more block-rows than resident workgroups);
+//   * the off-diagonal tiles of a block-row are consumed as soon as the x block they need is published, i.e. all
+//     but the last one long before the chain arrives; their matrix elements are loaded BEFORE the wait;
+//   * per row the running sum lives in a register expansion per (wave, lane) and spills to the row's private
+//     integer accumulator in LDS (68 limbs, pitch 69 words: a wave adding to the same limb of 64 rows, the common
+//     case, touches 64 different banks);
+//   * the diagonal block is solved by ONE wave, registers + LDS only: per row a wave-parallel carry resolution and
+//     rounding of the row's 68 limbs (finish_wave<false>: shuffles and ballots, no barrier), one fp64 division,
+//     and one TwoProd per remaining row.
+// Cross-workgroup traffic: x values are written and read with agent-scope relaxed atomics (they bypass the
+// non-coherent cache levels), the "blocks done" counter with release / acquire.
+#include "exblas_internal.h"
+#include "fpe.hip.h"
+
+namespace exb {
+namespace {
+
+constexpr int TB = 64;            // rows per block-row = lanes of a wave
+constexpr int TW = 4;             // waves per workgroup
+constexpr int TCW = TB / TW;      // tile columns per wave
+constexpr int TPITCH = NL + 1;    // int64 words per row accumulator (odd)
+static_assert(TCW == 16, "the tile loop below is written for 2 x 8 columns per wave");
+
+// one row's accumulator in LDS, limbs contiguous
+struct RowSink {
+    long long *row;
+    unsigned *flagp;
+    __device__ __forceinline__ void add(double x)
+    {
+        unsigned f = 0;
+        lds_add<1>(row, x, f);
+        if (f) atomicOr(flagp, f);  // Inf / NaN: rare
+    }
+};
+
+__device__ __forceinline__ double ld_coherent(const double *p)
+{
+    return __longlong_as_double(__hip_atomic_load((const long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void st_coherent(double *p, double v)
+{
+    __hip_atomic_store((long long *)p, __double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Blocks until `done` (number of finished block-rows) exceeds C.  Thread 0 polls, everybody learns the value read
+// through LDS, so that already-finished blocks cost no further global access.  `known` is workgroup-uniform.
+__device__ __forceinline__ void wait_block(const int *done, int C, int &known, int *s_known, int &parity)
+{
+    if (C < known) return;
+    if (threadIdx.x == 0) {
+        int v;
+        while ((v = __hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) <= C)
+            __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // pairs with the publisher's release
+        s_known[parity] = v;
+    }
+    __syncthreads();
+    known = s_known[parity];
+    parity ^= 1;  // a thread can lag at most one wait behind thread 0: two slots are enough
+}
+
+// ---------------------------------------------------------------------------------------------
+// the exact solve.  Logical indices run in substitution order; phys() maps them to storage (reversed for
+// backward substitution).  Element (row r, column c) of the logical matrix is a[phys(r)*rs + phys(c)*cs].
+// sync[0]: block-row ticket, sync[1]: block-rows done.
+// ---------------------------------------------------------------------------------------------
+template <int N, bool EE>
+__global__ void __launch_bounds__(TB *TW) k_trsv(int n, const double *__restrict__ a, long long rs, long long cs,
+                                                 double *x, long long incx, int rev, int unit, int mode, int *sync)
+{
+    __shared__ long long acc[TB * TPITCH];
+    __shared__ double dg[TB * TB];  // diagonal block, dg[c * TB + r], strictly-lower part
+    __shared__ unsigned rflags[TB];
+    __shared__ int s_row, s_known[2];
+    const int tid = (int)threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid == 0) s_row = atomicAdd(&sync[0], 1);
+    for (int i = tid; i < TB * TPITCH; i += TB * TW) acc[i] = 0;
+    if (tid < TB) rflags[tid] = 0;
+    __syncthreads();
+    const int R = s_row, base = R * TB;
+    const int r = base + lane;
+    const bool active = r < n;
+    auto phys = [&](int k) -> long long { return rev ? (long long)(n - 1 - k) : (long long)k; };
+    const long long rp = phys(active ? r : base);
+    const double *arow = a + rp * rs;
+
+    for (int cc = w * TCW; cc < (w + 1) * TCW; ++cc) {
+        double v = 0.0;
+        if (active && cc < lane) v = arow[phys(base + cc) * cs];
+        dg[cc * TB + lane] = v;
+    }
+    double dv = 1.0, rhs = 0.0;
+    if (w == 0 && active) {
+        if (!unit) dv = arow[rp * cs];
+        rhs = x[rp * incx];  // written before the launch, replaced by this workgroup only
+    }
+
+    double f[N > 0 ? N : 1];
+#pragma unroll
+    for (int i = 0; i < (N > 0 ? N : 1); ++i) f[i] = 0.0;
+    RowSink sink{acc + lane * TPITCH, &rflags[lane]};
+    int bypass = 0, known = 0, parity = 0;
+
+    for (int C = 0; C < R; ++C) {
+        const int c0 = C * TB + w * TCW;
+        double av[TCW];
+#pragma unroll
+        for (int u = 0; u < TCW; ++u)
+            av[u] = active ? __builtin_nontemporal_load(arow + phys(c0 + u) * cs) : 0.0;
+        wait_block(&sync[1], C, known, s_known, parity);
+        double xl = 0.0;
+        if (lane < TCW) xl = ld_coherent(x + phys(c0 + lane) * incx);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            double p[8], e[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) p[u] = two_prod(av[h * 8 + u], -__shfl(xl, h * 8 + u), e[u]);
+            fpe_absorb_prod_adaptive<N, EE, 8>(f, p, e, sink, bypass);
+        }
+    }
+    fpe_flush_sink<N>(f, sink);
+    if (w == 0 && active) sink.add(rhs);
+    __syncthreads();
+    if (w != 0) return;
+
+    // ---- diagonal block: one wave, one row at a time ----
+    const int rows = min(TB, n - base);
+    double xs = 0.0;
+    for (int i = 0; i < rows; ++i) {
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);  // the row reads below follow this wave's LDS adds in program order
+        const long long v0 = acc[i * TPITCH + lane], v1 = lane < NL - 64 ? acc[i * TPITCH + 64 + lane] : 0;
+        const unsigned fl = rflags[i];
+        double v;
+        if (mode) v = finish_wave<true>(v0, v1, fl).rf;
+        else v = __longlong_as_double((long long)finish_wave<false>(v0, v1, fl).ex);
+        if (!unit) v = v / __shfl(dv, i);
+        if (lane == i) xs = v;
+        if (lane > i && active) {
+            double e;
+            const double p = two_prod(dg[i * TB + lane], -v, e);
+            sink.add(p);
+            if (e != 0.0 && expo_field(p) != 0x7ffu) sink.add(e);
+        }
+    }
+    if (active) st_coherent(x + rp * incx, xs);
+    __threadfence();  // x is visible device-wide before the counter moves
+    if (lane == 0) __hip_atomic_store(&sync[1], R + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---------------------------------------------------------------------------------------------
+// fpe == 1: the plain fp64 solve (DTRSV.lnn.cl / DTRSV.unn.cl), same blocking.  Not exact, but deterministic here:
+// the partial sums of the 4 waves are combined in a fixed order.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(TB *TW) k_dtrsv(int n, const double *__restrict__ a, long long rs, long long cs,
+                                                  double *x, long long incx, int rev, int unit, int *sync)
+{
+    __shared__ double dg[TB * TB];
+    __shared__ double part[TW][TB];
+    __shared__ int s_row, s_known[2];
+    const int tid = (int)threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid == 0) s_row = atomicAdd(&sync[0], 1);
+    __syncthreads();
+    const int R = s_row, base = R * TB;
+    const int r = base + lane;
+    const bool active = r < n;
+    auto phys = [&](int k) -> long long { return rev ? (long long)(n - 1 - k) : (long long)k; };
+    const long long rp = phys(active ? r : base);
+    const double *arow = a + rp * rs;
+    for (int cc = w * TCW; cc < (w + 1) * TCW; ++cc) {
+        double v = 0.0;
+        if (active && cc < lane) v = arow[phys(base + cc) * cs];
+        dg[cc * TB + lane] = v;
+    }
+    double s = 0.0;
+    int known = 0, parity = 0;
+    for (int C = 0; C < R; ++C) {
+        const int c0 = C * TB + w * TCW;
+        double av[TCW];
+#pragma unroll
+        for (int u = 0; u < TCW; ++u)
+            av[u] = active ? __builtin_nontemporal_load(arow + phys(c0 + u) * cs) : 0.0;
+        wait_block(&sync[1], C, known, s_known, parity);
+        double xl = 0.0;
+        if (lane < TCW) xl = ld_coherent(x + phys(c0 + lane) * incx);
+#pragma unroll
+        for (int u = 0; u < TCW; ++u) s -= av[u] * __shfl(xl, u);
+    }
+    part[w][lane] = s;
+    __syncthreads();
+    if (w != 0) return;
+    double t = active ? x[rp * incx] : 0.0;
+    t = ((t + part[0][lane]) + part[1][lane]) + (part[2][lane] + part[3][lane]);
+    double dv = 1.0;
+    if (active && !unit) dv = arow[rp * cs];
+    const int rows = min(TB, n - base);
+    for (int i = 0; i < rows; ++i) {
+        if (lane == i && !unit) t = t / dv;
+        const double v = __shfl(t, i);
+        if (lane > i && active) t -= dg[i * TB + lane] * v;
+    }
+    if (active) st_coherent(x + rp * incx, t);
+    __threadfence();
+    if (lane == 0) __hip_atomic_store(&sync[1], R + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int N, bool EE>
+hipError_t trsv_variant(int n, const double *a, long long rs, long long cs, double *x, long long incx, int rev, int unit,
+                        int mode, int *sync, hipStream_t st)
+{
+    hipLaunchKernelGGL((k_trsv<N, EE>), dim3((n + TB - 1) / TB), dim3(TB * TW), 0, st, n, a, rs, cs, x, incx, rev, unit,
+                       mode, sync);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+// variant selection: ExTRSV.cpp:70-123.  Returns hipErrorNotSupported for the iterative-refinement values of fpe
+// (>= 9), whose kernel files the reference names but does not ship.
+hipError_t extrsv_dispatch(Ctx &c, char uplo, char transa, char diag, int n, const double *a, int lda, double *x,
+                           int incx, int fpe, int early_exit, int round_mode, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    if (fpe < 0 || fpe >= 9) return hipErrorNotSupported;
+    const bool lower = (uplo == 'L' || uplo == 'l'), trans = (transa == 'T' || transa == 't');
+    const int unit = (diag == 'U' || diag == 'u') ? 1 : 0;
+    const int rev = (lower != trans) ? 0 : 1;  // A**T of a lower matrix is upper: backward substitution
+    const long long rs = trans ? (long long)lda : 1ll, cs = trans ? 1ll : (long long)lda;
+    int *sync = (int *)workspace(c, 2 * sizeof(int));
+    hipError_t e = hipMemsetAsync(sync, 0, 2 * sizeof(int), st);
+    if (e != hipSuccess) return e;
+#define TV_ARGS n, a, rs, cs, x, (long long)incx, rev, unit, round_mode, sync, st
+    if (fpe == 0) return trsv_variant<0, false>(TV_ARGS);
+    if (fpe == 1) {
+        hipLaunchKernelGGL(k_dtrsv, dim3((n + TB - 1) / TB), dim3(TB * TW), 0, st, n, a, rs, cs, x, (long long)incx, rev,
+                           unit, sync);
+        return hipGetLastError();
+    }
+    if (early_exit) {
+        if (fpe <= 4) return trsv_variant<4, true>(TV_ARGS);
+        if (fpe <= 6) return trsv_variant<6, true>(TV_ARGS);
+        return trsv_variant<8, true>(TV_ARGS);
+    }
+    switch (fpe) {
+    case 2: return trsv_variant<2, false>(TV_ARGS);
+    case 3: return trsv_variant<3, false>(TV_ARGS);
+    case 4: return trsv_variant<4, false>(TV_ARGS);
+    case 5: return trsv_variant<5, false>(TV_ARGS);
+    case 6: return trsv_variant<6, false>(TV_ARGS);
+    case 7: return trsv_variant<7, false>(TV_ARGS);
+    default: return trsv_variant<8, false>(TV_ARGS);
+    }
+#undef TV_ARGS
+}
+
+}  // namespace exb

@@ -112,6 +112,15 @@ int exblas_finalize_dev(const int64_t *d_digit_sets, int nsets, uint32_t flags_o
 int exblas_exgemv_dev(char transa, int m, int n, double alpha, const double *d_a, int lda,
                       const double *d_x, int incx, double beta, double *d_y, int incy, int fpe,
                       int early_exit, void *stream);
+/* ExTRSV on device pointers, column-major A (ExTRSV.Launcher.hpp; kernels trsv_init/trsv,
+ * ExTRSV.lnn.Superacc.cl:241-348, ExTRSV.unn.Superacc.cl:249-355).  d_x holds b on entry and the solution on
+ * return: x_i = fl(Round(b_i - sum_j A(i,j) x_j) / A(i,i)), the sum exact.  uplo 'L'/'U', transa 'N'/'T',
+ * diag 'N'/'U' (unit diagonal: not read).  fpe as ExTRSV.cpp:70-123: 0 superaccumulators, 1 plain DTRSV,
+ * 2..8 expansions (early_exit: buckets 4/6/8); returns EXBLAS_UNSUPPORTED (-1) for fpe >= 9, the
+ * iterative-refinement variants whose kernel files the reference does not ship.  Other non-zero: a hipError_t. */
+#define EXBLAS_UNSUPPORTED (-1)
+int exblas_extrsv_dev(char uplo, char transa, char diag, int n, const double *d_a, int lda, double *d_x,
+                      int incx, int fpe, int early_exit, void *stream);
 /* ExGEMM on device pointers, row-major (ExGEMM.Launcher.hpp; kernel gemm, ExGEMM.Superacc.cl:200-283). */
 int exblas_exgemm_dev(char transa, char transb, int m, int n, int k, double alpha,
                       const double *d_a, int lda, const double *d_b, int ldb, double beta,
@@ -134,6 +143,9 @@ double exblas_exdot(int Ng, const double *ag, int inca, int offseta, const doubl
 int exblas_exgemv(char transa, int m, int n, double alpha, const double *a, int lda, int offseta,
                   const double *x, int incx, int offsetx, double beta, double *y, int incy,
                   int offsety, int fpe, int early_exit);
+/* blas2.hpp:57 extrsv; returns 0, or -1 (message on stderr, x untouched) for fpe >= 9 */
+int exblas_extrsv(char uplo, char transa, char diag, int n, const double *a, int lda, int offseta, double *x,
+                  int incx, int offsetx, int fpe, int early_exit);
 int exblas_exgemm(char transa, char transb, int m, int n, int k, double alpha, const double *a,
                   int lda, const double *b, int ldb, double beta, double *c, int ldc, int fpe,
                   int early_exit);

@@ -639,6 +639,77 @@ int orc_exgemm(char transa, char transb, int m, int n, int k, double alpha, cons
 }
 
 /* ------------------------------------------------------------------------------------------
+ * ExTRSV (ExTRSV.cpp:70-123 dispatch; kernels ExTRSV.lnn.Superacc.cl:254-348 lower,
+ * ExTRSV.unn.Superacc.cl:262-355 upper), column-major A, solves A x = b in place (x holds b):
+ *     x_i = fl( Round( b_i - sum_j A(i,j) * x_j ) / A(i,i) ),   j < i (lower) or j > i (upper),
+ * rows in dependency order; the sum is exact (TwoProductFMA into the superaccumulator,
+ * lnn.Superacc.cl:305-311,:331-336), Round is the superaccumulator rounding, the division an
+ * ordinary fp64 one (:326-328) -- so x_i carries two roundings, by design of the reference.
+ * The reference kernels ignore transa and diag (isunit = 0, lnn.Superacc.cl:272; they always
+ * divide by the stored diagonal, which init_*_tr_matrix sets to 1 for diag == 'U') and incx /
+ * the offsets; we restate the BLAS meaning of all of them ('T': A(i,j) is read at a[i*lda+j];
+ * diag == 'U': the diagonal is not read).  fpe == 1 is the plain, non-reproducible DTRSV
+ * (ExTRSV.cpp:76-77).  fpe >= 9 names iterative-refinement kernel files the reference does not
+ * ship (ExTRSV.cpp:91-120; no *.IR.cl / *.ExIR.*.cl under src/gpu/blas/blas2): returns -1.
+ * Parity: no CPU ExTRSV exists in the reference and its OpenCL path cannot run here, so this
+ * function is pinned by MPFR only (mpfr_oracle.c:mpfr_extrsv, bit for bit) and by the
+ * reference test's own criterion (test.extrsv.gpu.cpp:27-92, inf-norm error <= 1e-13).
+ * ---------------------------------------------------------------------------------------- */
+int orc_extrsv(char uplo, char transa, char diag, int n, const double *a, int lda, int offseta,
+               double *x, int incx, int offsetx, int fpe, int early_exit, int round_mode)
+{
+    if (fpe < 0 || fpe >= 9) return -1;
+    int nfpe;
+    if (fpe == 0) nfpe = 0;
+    else if (fpe == 1) nfpe = -2;
+    else if (early_exit) nfpe = fpe <= 4 ? 4 : (fpe <= 6 ? 6 : 8); /* ExTRSV.cpp:79-86 */
+    else nfpe = fpe;                                                 /* ExTRSV.cpp:87-88, NBFPE = fpe % 10 */
+    const int lower = (uplo == 'L' || uplo == 'l');
+    const int trans = (transa == 'T' || transa == 't');
+    const int unit = (diag == 'U' || diag == 'u');
+    /* A**T of a lower matrix is upper and vice versa: the dependency order follows the logical shape */
+    const int fwd = lower != trans;
+    for (int s = 0; s < n; ++s) {
+        const int i = fwd ? s : n - 1 - s;
+        const int j0 = fwd ? 0 : i + 1, j1 = fwd ? i : n;
+        double *xi = &x[offsetx + (int64_t)i * incx];
+        double v;
+        if (nfpe == -2) {
+            v = *xi;
+            for (int j = j0; j < j1; ++j) {
+                double av = trans ? a[offseta + (int64_t)i * lda + j] : a[offseta + i + (int64_t)lda * j];
+                v -= av * x[offsetx + (int64_t)j * incx];
+            }
+        } else {
+            orc_superacc sa;
+            orc_sa_init(&sa);
+            orc_fpe1 f;
+            memset(&f, 0, sizeof(f));
+            f.n = nfpe;
+            f.early_exit = early_exit;
+            f.sa = &sa;
+            for (int j = j0; j < j1; ++j) {
+                double av = trans ? a[offseta + (int64_t)i * lda + j] : a[offseta + i + (int64_t)lda * j];
+                double r, p = orc_two_prod(av, -x[offsetx + (int64_t)j * incx], &r);
+                if (nfpe == 0) {
+                    orc_sa_accumulate(&sa, p);
+                    if (r != 0.0) orc_sa_accumulate(&sa, r);
+                } else {
+                    orc_fpe1_add(&f, p, 0);
+                    if (r != 0.0) orc_fpe1_add(&f, r, nfpe >= 3 ? nfpe - 3 : 0);
+                }
+            }
+            if (nfpe > 0) orc_fpe1_flush_all(&f);
+            orc_sa_accumulate(&sa, *xi);
+            v = (round_mode == ORC_ROUND_REFERENCE) ? orc_sa_round_reference(&sa) : orc_sa_round_exact(&sa);
+        }
+        if (!unit) v = v / a[offseta + (int64_t)i * lda + i];
+        *xi = v;
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
  * Generators
  * ---------------------------------------------------------------------------------------- */
 void orc_srand(unsigned seed) { srand(seed); }

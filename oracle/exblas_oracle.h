@@ -72,6 +72,10 @@ int orc_exgemv(char transa, int m, int n, double alpha, const double *a, int lda
 int orc_exgemm(char transa, char transb, int m, int n, int k, double alpha, const double *a,
                int lda, const double *b, int ldb, double beta, double *c, int ldc, int fpe,
                int early_exit, int round_mode);
+/* x := A^-1 x (or A^-T x), A triangular, column-major; returns -1 for the fpe values (>= 9) whose kernels the
+ * reference does not ship */
+int orc_extrsv(char uplo, char transa, char diag, int n, const double *a, int lda, int offseta,
+               double *x, int incx, int offsetx, int fpe, int early_exit, int round_mode);
 
 /* Input generators.  The *_rand ones follow src/common/common.cpp and draw from glibc
  * rand() (call srand() first for a fixed stream); the *_ctr ones are our counter-based

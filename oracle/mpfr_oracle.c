@@ -93,3 +93,42 @@ void mpfr_exgemm_dots(int m, int n, int k, const double *a, int lda, const doubl
     mpfr_clear(dot);
     mpfr_clear(sum);
 }
+
+/* tests/test.extrsv.gpu.cpp:27-66, column-major, x holds b on entry.  two_step != 0: the sum
+ * (exact: 4196 bits, 128-bit products) is rounded to double and then divided in fp64, which is
+ * what the reference kernels compute (ExTRSV.lnn.Superacc.cl:323-328); two_step == 0: the
+ * reference test's own oracle, which divides inside MPFR and rounds once -- the two differ by
+ * an ulp now and then, hence the test's 1e-13 tolerance (:141). */
+void mpfr_extrsv(char uplo, char trans, char diag, int n, const double *a, int lda, double *x, int incx,
+                 int two_step)
+{
+    mpfr_t sum, dot;
+    mpfr_init2(dot, 128);
+    mpfr_init2(sum, 4196);
+    const int lower = (uplo == 'L'), tr = (trans == 'T'), unit = (diag == 'U');
+    const int fwd = lower != tr;
+    for (int s = 0; s < n; s++) {
+        const int i = fwd ? s : n - 1 - s;
+        const int j0 = fwd ? 0 : i + 1, j1 = fwd ? i : n;
+        mpfr_set_d(sum, 0.0, MPFR_RNDN);
+        for (int j = j0; j < j1; j++) {
+            double av = tr ? a[(long)i * lda + j] : a[(long)j * lda + i];
+            mpfr_set_d(dot, av, MPFR_RNDN);
+            mpfr_mul_d(dot, dot, -x[(long)j * incx], MPFR_RNDN);
+            mpfr_add(sum, sum, dot, MPFR_RNDN);
+        }
+        mpfr_add_d(sum, sum, x[(long)i * incx], MPFR_RNDN);
+        double v;
+        if (two_step) {
+            v = mpfr_get_d(sum, MPFR_RNDN);
+            if (!unit) v = v / a[(long)i * lda + i];
+        } else {
+            if (!unit) mpfr_div_d(sum, sum, a[(long)i * lda + i], MPFR_RNDN);
+            v = mpfr_get_d(sum, MPFR_RNDN);
+        }
+        x[(long)i * incx] = v;
+    }
+    mpfr_clear(dot);
+    mpfr_clear(sum);
+    mpfr_free_cache();
+}

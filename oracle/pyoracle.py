@@ -45,6 +45,9 @@ def lib():
         L.orc_exgemv.argtypes = [C.c_char, C.c_int, C.c_int, C.c_double, _dp, C.c_int, C.c_int, _dp, C.c_int,
                                  C.c_int, C.c_double, _dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         L.orc_exgemm.restype = C.c_int
+        L.orc_extrsv.restype = C.c_int
+        L.orc_extrsv.argtypes = [C.c_char, C.c_char, C.c_char, C.c_int, _dp, C.c_int, C.c_int, _dp, C.c_int, C.c_int,
+                                 C.c_int, C.c_int, C.c_int]
         L.orc_exgemm.argtypes = [C.c_char, C.c_char, C.c_int, C.c_int, C.c_int, C.c_double, _dp, C.c_int, _dp,
                                  C.c_int, C.c_double, _dp, C.c_int, C.c_int, C.c_int, C.c_int]
         L.orc_round_limbs.restype = C.c_double
@@ -120,6 +123,14 @@ def exgemm(transa, transb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, fpe=0, 
     lib().orc_exgemm(transa.encode(), transb.encode(), m, n, k, alpha, np.ascontiguousarray(a, dtype=np.float64),
                      lda, np.ascontiguousarray(b, dtype=np.float64), ldb, beta, c, ldc, fpe, int(early_exit), mode)
     return c
+
+
+def extrsv(uplo, trans, diag, n, a, lda, x, fpe=0, early_exit=False, incx=1, offa=0, offx=0, mode=ROUND_EXACT):
+    """returns (rc, solution); x is copied"""
+    x = np.array(x, dtype=np.float64, copy=True)
+    rc = lib().orc_extrsv(uplo.encode(), trans.encode(), diag.encode(), n, np.ascontiguousarray(a, dtype=np.float64),
+                          lda, offa, x, incx, offx, fpe, int(early_exit), mode)
+    return rc, x
 
 
 def round_limbs(limbs, mode=ROUND_EXACT):
@@ -238,6 +249,7 @@ def mpfr():
         L.mpfr_exgemv.argtypes = [C.c_char, C.c_int, C.c_int, C.c_double, _dp, C.c_int, _dp, C.c_int, C.c_double,
                                   _dp, C.c_int, _dp]
         L.mpfr_exgemm_dots.argtypes = [C.c_int, C.c_int, C.c_int, _dp, C.c_int, _dp, C.c_int, _dp, C.c_int]
+        L.mpfr_extrsv.argtypes = [C.c_char, C.c_char, C.c_char, C.c_int, _dp, C.c_int, _dp, C.c_int, C.c_int]
         _mpfr = L
     return _mpfr
 
@@ -271,3 +283,10 @@ def mpfr_exgemm_dots(m, n, k, a, lda, b, ldb):
     mpfr().mpfr_exgemm_dots(m, n, k, np.ascontiguousarray(a, dtype=np.float64), lda,
                             np.ascontiguousarray(b, dtype=np.float64), ldb, out, n)
     return out
+
+
+def mpfr_extrsv(uplo, trans, diag, n, a, lda, b, two_step=True):
+    x = np.array(b, dtype=np.float64, copy=True)
+    mpfr().mpfr_extrsv(uplo.encode(), trans.encode(), diag.encode(), n, np.ascontiguousarray(a, dtype=np.float64), lda,
+                       x, 1, int(two_step))
+    return x
