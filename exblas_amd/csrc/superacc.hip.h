@@ -273,6 +273,53 @@ __device__ inline void finish_record(long long *v, unsigned flags, long long *ou
 // All 64 lanes must call it.  Same bits as the single-thread finish_record above (the scalar ExGEMM kernel still
 // uses that one; the parity tests run both against the oracle).
 // ---------------------------------------------------------------------------------------------
+// cross-lane moves that stay in the VALU / SALU (no LDS crossbar round trip as with __shfl):
+// wave_shr1: lane l receives lane l-1's value, lane 0 receives 0 (DPP wave_shr:1, GFX9 family);
+// lane_bcast: every lane receives lane `l`'s value, l wave-uniform (v_readlane)
+__device__ __forceinline__ long long wave_shr1(long long v)
+{
+    int lo = (int)v, hi = (int)(v >> 32);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, true);
+    return (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo);
+}
+__device__ __forceinline__ unsigned lane_bcast(unsigned v, int l) { return (unsigned)__builtin_amdgcn_readlane((int)v, l); }
+__device__ __forceinline__ long long lane_bcast(long long v, int l)
+{
+    const unsigned lo = lane_bcast((unsigned)v, l), hi = lane_bcast((unsigned)(v >> 32), l);
+    return (long long)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ double lane_bcast(double v, int l)
+{
+    return __longlong_as_double(lane_bcast(__double_as_longlong(v), l));
+}
+
+// Adds the wave-uniform double x to an accumulator held across the wave (lane l: limb l in v0, lanes 0..3: limbs
+// 64..67 in v1) -- the register twin of lds_add.
+__device__ __forceinline__ void wave_add_double(long long &v0, long long &v1, double x, unsigned &flags)
+{
+    const int lane = (int)(threadIdx.x & 63u);
+    const unsigned long long u = (unsigned long long)__double_as_longlong(x);
+    unsigned be = (unsigned)(u >> 52) & 0x7ffu;
+    unsigned long long m = u & 0x000fffffffffffffull;
+    if (be == 0x7ffu) {
+        flags |= m ? FLAG_NAN : ((u >> 63) ? FLAG_NINF : FLAG_PINF);
+        return;
+    }
+    if (be) m |= 0x0010000000000000ull; else be = 1u;
+    const unsigned p = be - 1u;
+    const int idx = (int)(p >> 5);
+    const unsigned sh = p & 31u;
+    const unsigned long long lo = m << sh;
+    const unsigned hi = (unsigned)((m >> 32) >> (32u - sh));
+    long long c0 = (long long)(lo & 0xffffffffull), c1 = (long long)(lo >> 32), c2 = (long long)hi;
+    if (u >> 63) { c0 = -c0; c1 = -c1; c2 = -c2; }
+    const int k0 = lane - idx;        // limb `lane` takes chunk k0 when 0 <= k0 <= 2
+    const int k1 = lane + 64 - idx;   // limb 64 + lane
+    v0 += k0 == 0 ? c0 : (k0 == 1 ? c1 : (k0 == 2 ? c2 : 0ll));
+    if (lane < NL - 64) v1 += k1 == 0 ? c0 : (k1 == 1 ? c1 : (k1 == 2 ? c2 : 0ll));
+}
+
 struct WaveFinish {
     unsigned long long ex;  // bits of the correctly rounded double (uniform)
     double rf;              // reference-compatible rounding (uniform)
@@ -297,9 +344,9 @@ __device__ inline WaveFinish finish_wave(long long v0, long long v1, const unsig
     for (int pass = 0; pass < 2 * NL && hi >= 0; ++pass) {
         const long long c0 = split0 ? (v0 >> 32) : 0, lo0 = split0 ? (v0 & 0xffffffffll) : v0;
         const long long c1 = split1 ? (v1 >> 32) : 0, lo1 = split1 ? (v1 & 0xffffffffll) : v1;
-        long long in0 = __shfl_up(c0, 1), in1 = __shfl_up(c1, 1);
-        const long long c63 = __shfl(c0, 63);
-        if (lane == 0) { in0 = 0; in1 = c63; }
+        long long in0 = wave_shr1(c0), in1 = wave_shr1(c1);
+        const long long c63 = lane_bcast(c0, 63);
+        if (lane == 0) in1 = c63;
         v0 = lo0 + in0;
         v1 = (lane < HI) ? lo1 + in1 : 0;
         const bool pending = (split0 && (v0 >> 32) != 0) || (split1 && (v1 >> 32) != 0);
@@ -307,7 +354,7 @@ __device__ inline WaveFinish finish_wave(long long v0, long long v1, const unsig
     }
     if (hi >= 0 && hi + 1 < NL - 1) {  // sign-extend limb hi+1 through the empty limbs up to the top one
         const int e = hi + 1;
-        const long long s0 = __shfl(v0, e & 63), s1 = __shfl(v1, (e - 64) & 63);
+        const long long s0 = lane_bcast(v0, e & 63), s1 = lane_bcast(v1, (e - 64) & 63);
         const long long sv = e < 64 ? s0 : s1;
         const long long fill = sv < 0 ? 0xffffffffll : 0ll;
         if (lane == e) v0 = sv & 0xffffffffll;
@@ -321,7 +368,7 @@ __device__ inline WaveFinish finish_wave(long long v0, long long v1, const unsig
     WaveFinish r;
     r.d0 = v0;
     r.d1 = v1;
-    const long long top = __shfl(v1, HI - 1);
+    const long long top = lane_bcast(v1, HI - 1);
     const bool neg = top < 0;
     const unsigned d0 = (unsigned)v0, d1 = (unsigned)v1;
     // ---- magnitude digits ----
@@ -333,7 +380,7 @@ __device__ inline WaveFinish finish_wave(long long v0, long long v1, const unsig
     const unsigned long long mz0 = __ballot(m0 != 0), mz1 = __ballot(m1 != 0);
     const int tp = mz1 ? 64 + (63 - __builtin_clzll(mz1)) : (mz0 ? 63 - __builtin_clzll(mz0) : -1);
     auto mag = [&](int i) -> unsigned {  // i uniform
-        const unsigned a = __shfl(m0, i & 63), b = __shfl(m1, (i - 64) & 63);
+        const unsigned a = lane_bcast(m0, i & 63), b = lane_bcast(m1, (i - 64) & 63);
         return i < 0 ? 0u : (i < 64 ? a : b);
     };
     unsigned long long ex = 0ull;

@@ -57,6 +57,68 @@ __device__ __forceinline__ void st_coherent(double *p, double v)
     __hip_atomic_store((long long *)p, __double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+constexpr int DG_M = 4;    // expansion levels per row in the diagonal phase
+constexpr int DG_K = 6;    // limbs below a row's leading limb that row_to_fpe moves into the expansion
+
+// x enters levels FROM..DG_M-1 of g; what is left after the last level goes to the row's integer accumulator
+// (exactly) and into its bound B (rounded up)
+template <int FROM>
+__device__ __forceinline__ void fpe_push(double (&g)[DG_M], double &B, double x, RowSink &sink)
+{
+#pragma unroll
+    for (int k = FROM; k < DG_M; ++k) {
+        double r;
+        g[k] = two_sum(g[k], x, r);
+        x = r;
+    }
+    if (x != 0.0) {
+        sink.add(x);
+        B += fabs(x) * 1.0000001;
+    }
+}
+
+// Moves this lane's row of the LDS accumulator into the expansion g: the leading non-zero limb and the DG_K limbs
+// below it (at least 193 bits), top down; lower limbs stay where they are and only enter the bound B.  Rows that
+// saw Inf/NaN or hold anything at limb 62 or above (|value| >= 2^910) are left alone with B = inf, which sends
+// them to the integer path.  All 64 lanes must call it.
+__device__ inline void row_to_fpe(long long *row, unsigned rowflags, double (&g)[DG_M], double &B, RowSink &sink)
+{
+#pragma unroll
+    for (int k = 0; k < DG_M; ++k) g[k] = 0.0;
+    B = rowflags ? __builtin_inf() : 0.0;
+    // which limbs are non-zero in ANY row (wave-uniform): the reads are independent, so they pipeline
+    unsigned long long u0 = 0ull;
+    unsigned u1 = 0u;
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+        const bool nz = __any(row[l] != 0);
+        if (l < 64) u0 |= nz ? (1ull << l) : 0ull;
+        else u1 |= nz ? (1u << (l - 64)) : 0u;
+    }
+    int top = -1;
+    for (int l = NL - 1; l >= 0; --l) {
+        const bool on = l < 64 ? ((u0 >> l) & 1ull) != 0 : ((u1 >> (l - 64)) & 1u) != 0;
+        if (!on) continue;  // uniform
+        const long long v = row[l];
+        if (v == 0) continue;
+        if (l >= 62 || B == __builtin_inf()) {
+            B = __builtin_inf();
+            continue;
+        }
+        if (top < 0) top = l;
+        if (top - l <= DG_K) {
+            row[l] = 0;
+            // v = hi * 2^32 + lo, both halves exact in fp64; limb l has weight 2^(32 l - 1074)
+            const double xh = ldexp((double)(int)(v >> 32), 32 * l + 32 - 1074);
+            const double xl = ldexp((double)(unsigned)v, 32 * l - 1074);
+            fpe_push<0>(g, B, xh, sink);
+            fpe_push<0>(g, B, xl, sink);
+        } else {
+            B += ldexp(1.0, 32 * l + 64 - 1074);  // |v| < 2^63 at weight 2^(32 l - 1074)
+        }
+    }
+}
+
 // Blocks until `done` (number of finished block-rows) exceeds C.  Thread 0 polls, everybody learns the value read
 // through LDS, so that already-finished blocks cost no further global access.  `known` is workgroup-uniform.
 __device__ __forceinline__ void wait_block(const int *done, int C, int &known, int *s_known, int &parity)
@@ -129,7 +191,7 @@ __global__ void __launch_bounds__(TB *TW) k_trsv(int n, const double *__restrict
         for (int h = 0; h < 2; ++h) {
             double p[8], e[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) p[u] = two_prod(av[h * 8 + u], -__shfl(xl, h * 8 + u), e[u]);
+            for (int u = 0; u < 8; ++u) p[u] = two_prod(av[h * 8 + u], -lane_bcast(xl, h * 8 + u), e[u]);
             fpe_absorb_prod_adaptive<N, EE, 8>(f, p, e, sink, bypass);
         }
     }
@@ -141,20 +203,79 @@ __global__ void __launch_bounds__(TB *TW) k_trsv(int n, const double *__restrict
     // ---- diagonal block: one wave, one row at a time ----
     const int rows = min(TB, n - base);
     double xs = 0.0;
-    for (int i = 0; i < rows; ++i) {
-        __atomic_signal_fence(__ATOMIC_SEQ_CST);  // the row reads below follow this wave's LDS adds in program order
-        const long long v0 = acc[i * TPITCH + lane], v1 = lane < NL - 64 ? acc[i * TPITCH + 64 + lane] : 0;
-        const unsigned fl = rflags[i];
-        double v;
-        if (mode) v = finish_wave<true>(v0, v1, fl).rf;
-        else v = __longlong_as_double((long long)finish_wave<false>(v0, v1, fl).ex);
-        if (!unit) v = v / __shfl(dv, i);
-        if (lane == i) xs = v;
-        if (lane > i && active) {
-            double e;
-            const double p = two_prod(dg[i * TB + lane], -v, e);
-            sink.add(p);
-            if (e != 0.0 && expo_field(p) != 0x7ffu) sink.add(e);
+    if (mode != 0) {
+        // reference-compatible rounding: every row through the integer accumulator and the full finish_wave
+        for (int i = 0; i < rows; ++i) {
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);  // the row reads follow this wave's LDS adds in program order
+            const long long v0 = acc[i * TPITCH + lane], v1 = lane < NL - 64 ? acc[i * TPITCH + 64 + lane] : 0;
+            double v = finish_wave<true>(v0, v1, rflags[i]).rf;
+            if (!unit) v = v / lane_bcast(dv, i);
+            if (lane == i) xs = v;
+            if (lane > i && active) {
+                double e;
+                const double p = two_prod(dg[i * TB + lane], -v, e);
+                sink.add(p);
+                if (e != 0.0 && expo_field(p) != 0x7ffu) sink.add(e);
+            }
+        }
+    } else {
+        // Exact rounding, register fast path.  A lone wave retires roughly one instruction per 6-8 cycles, so the
+        // chain is priced in INSTRUCTIONS per row; the integer route (2 x lds_add, LDS round trip, wave-wide
+        // carry resolution and rounding, ~400 instructions) is replaced by a DG_M-level expansion per lane:
+        //     value of row j  =  g_j[0] + ... + g_j[DG_M-1]  +  (row j of the LDS accumulator),   |LDS part| <= B_j
+        // holds exactly at every step.  row_to_fpe moves the limbs gathered by the tile phase into g (once per
+        // block, all rows at a time); every x_i then costs each later row one TwoProd and two TwoSum cascades.
+        // At its turn a row folds g bottom-up into s with TwoSum: total = s + (sum of the errors) + LDS part, so
+        // when sum|errors| + B is below half the distance from s to its nearer neighbour, s IS the correctly
+        // rounded total (one double, no tie possible).  Otherwise -- near-ties, cancellation down to the noise,
+        // huge / tiny / non-finite values -- the row is flushed to LDS and rounded by the integer path.
+        double g[DG_M], B = 0.0;
+        row_to_fpe(acc + lane * TPITCH, rflags[lane], g, B, sink);
+        double acol = dg[lane];
+        for (int i = 0; i < rows; ++i) {
+            // ---- row i's turn (every lane evaluates its own row; lane i's answer is taken) ----
+            double s = g[DG_M - 1], err = 0.0;
+#pragma unroll
+            for (int k = DG_M - 2; k >= 0; --k) {
+                double e;
+                s = two_sum(g[k], s, e);
+                err += fabs(e);
+            }
+            const double as = fabs(s);
+            const double gap = as - __longlong_as_double(__double_as_longlong(as) - 1);  // to the neighbour towards 0
+            const unsigned be = expo_field(s);
+            bool ok = (err + B) * 1.0000001 < 0.5 * gap && be > 128u && be < BIG_EXPO;
+            if (s == 0.0 && err == 0.0 && B == 0.0) { ok = true; s = 0.0; }
+            double v;
+            if ((__ballot(ok) >> i) & 1ull) {
+                v = lane_bcast(s, i);
+            } else {
+                if (lane == i) {
+#pragma unroll
+                    for (int k = 0; k < DG_M; ++k)
+                        if (g[k] != 0.0) sink.add(g[k]);
+                }
+                __atomic_signal_fence(__ATOMIC_SEQ_CST);
+                const long long v0 = acc[i * TPITCH + lane], v1 = lane < NL - 64 ? acc[i * TPITCH + 64 + lane] : 0;
+                v = __longlong_as_double((long long)finish_wave<false>(v0, v1, rflags[i]).ex);
+            }
+            if (!unit) v = v / lane_bcast(dv, i);
+            if (lane == i) xs = v;
+            // ---- rows below take their product with x_i ----
+            const double ac = acol;
+            if (i + 1 < rows) acol = dg[(i + 1) * TB + lane];
+            if (lane > i && active) {
+                double e;
+                const double p = two_prod(ac, -v, e);
+                if (expo_field(p) >= BIG_EXPO) {  // too big for TwoSum, Inf or NaN: the integer side takes it
+                    sink.add(p);
+                    if (e != 0.0 && expo_field(p) != 0x7ffu) sink.add(e);
+                    B = __builtin_inf();
+                } else {
+                    fpe_push<0>(g, B, p, sink);
+                    fpe_push<1>(g, B, e, sink);
+                }
+            }
         }
     }
     if (active) st_coherent(x + rp * incx, xs);
@@ -198,7 +319,7 @@ __global__ void __launch_bounds__(TB *TW) k_dtrsv(int n, const double *__restric
         double xl = 0.0;
         if (lane < TCW) xl = ld_coherent(x + phys(c0 + lane) * incx);
 #pragma unroll
-        for (int u = 0; u < TCW; ++u) s -= av[u] * __shfl(xl, u);
+        for (int u = 0; u < TCW; ++u) s -= av[u] * lane_bcast(xl, u);
     }
     part[w][lane] = s;
     __syncthreads();
