@@ -31,6 +31,7 @@ C_ABI_SYMBOLS = [
     "exblas_exsum_accumulate_dev", "exblas_exdot_accumulate_dev", "exblas_finish_dev", "exblas_set_tuning",
     "exblas_set_gemm_path", "exblas_last_gemm_slices", "exblas_exsum_segmented_dev",
     "exblas_set_accumulator_slot", "exblas_stream_read2_dev", "exblas_extrsv_dev", "exblas_extrsv",
+    "exblas_extrsv_last_slow_rows",
 ]
 
 _lib = None

@@ -394,6 +394,17 @@ int exblas_extrsv_dev(char uplo, char transa, char diag, int n, const double *d_
                                 (hipStream_t)stream);
 }
 
+int exblas_extrsv_last_slow_rows(void)
+{
+    Ctx &c = ctx(-1);
+    std::lock_guard<std::mutex> lk(c.mu);
+    int v[4] = {0, 0, 0, 0};
+    if (!c.ws || c.ws_bytes < sizeof(v)) return -1;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpy(v, c.ws, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return v[2];
+}
+
 int exblas_exgemm_dev(char transa, char transb, int m, int n, int k, double alpha, const double *d_a, int lda,
                       const double *d_b, int ldb, double beta, double *d_c, int ldc, int fpe, int early_exit,
                       void *stream)

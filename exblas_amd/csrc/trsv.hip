@@ -71,7 +71,7 @@ __device__ __forceinline__ void fpe_push(double (&g)[DG_M], double &B, double x,
         g[k] = two_sum(g[k], x, r);
         x = r;
     }
-    if (x != 0.0) {
+    if (__builtin_expect(x != 0.0, 0)) {
         sink.add(x);
         B += fabs(x) * 1.0000001;
     }
@@ -139,7 +139,7 @@ __device__ __forceinline__ void wait_block(const int *done, int C, int &known, i
 // ---------------------------------------------------------------------------------------------
 // the exact solve.  Logical indices run in substitution order; phys() maps them to storage (reversed for
 // backward substitution).  Element (row r, column c) of the logical matrix is a[phys(r)*rs + phys(c)*cs].
-// sync[0]: block-row ticket, sync[1]: block-rows done.
+// sync[0]: block-row ticket, sync[1]: block-rows done, sync[2]: rows rounded by the integer path (statistics).
 // ---------------------------------------------------------------------------------------------
 template <int N, bool EE>
 __global__ void __launch_bounds__(TB *TW) k_trsv(int n, const double *__restrict__ a, long long rs, long long cs,
@@ -244,12 +244,14 @@ __global__ void __launch_bounds__(TB *TW) k_trsv(int n, const double *__restrict
             const double as = fabs(s);
             const double gap = as - __longlong_as_double(__double_as_longlong(as) - 1);  // to the neighbour towards 0
             const unsigned be = expo_field(s);
-            bool ok = (err + B) * 1.0000001 < 0.5 * gap && be > 128u && be < BIG_EXPO;
-            if (s == 0.0 && err == 0.0 && B == 0.0) { ok = true; s = 0.0; }
+            const double eb = err + B;
+            // eb == 0: the total IS s (any magnitude); otherwise s must be an ordinary normal number
+            const bool ok = (eb * 1.0000001 < 0.5 * gap && be > 128u && be < BIG_EXPO) || (eb == 0.0 && be < BIG_EXPO);
             double v;
-            if ((__ballot(ok) >> i) & 1ull) {
-                v = lane_bcast(s, i);
+            if (__builtin_expect((int)((__ballot(ok) >> i) & 1ull), 1)) {
+                v = lane_bcast(s, i) + 0.0;  // + 0.0: an exact zero total is +0 like the integer path's
             } else {
+                if (lane == 0) atomicAdd(&sync[2], 1);  // statistics: rows that took the integer path
                 if (lane == i) {
 #pragma unroll
                     for (int k = 0; k < DG_M; ++k)
@@ -267,13 +269,13 @@ __global__ void __launch_bounds__(TB *TW) k_trsv(int n, const double *__restrict
             if (lane > i && active) {
                 double e;
                 const double p = two_prod(ac, -v, e);
-                if (expo_field(p) >= BIG_EXPO) {  // too big for TwoSum, Inf or NaN: the integer side takes it
+                if (__builtin_expect(expo_field(p) >= BIG_EXPO, 0)) {  // too big for TwoSum, Inf or NaN: integer side
                     sink.add(p);
                     if (e != 0.0 && expo_field(p) != 0x7ffu) sink.add(e);
                     B = __builtin_inf();
                 } else {
                     fpe_push<0>(g, B, p, sink);
-                    fpe_push<1>(g, B, e, sink);
+                    fpe_push<DG_M - 2>(g, B, e, sink);
                 }
             }
         }
@@ -361,8 +363,8 @@ hipError_t extrsv_dispatch(Ctx &c, char uplo, char transa, char diag, int n, con
     const int unit = (diag == 'U' || diag == 'u') ? 1 : 0;
     const int rev = (lower != trans) ? 0 : 1;  // A**T of a lower matrix is upper: backward substitution
     const long long rs = trans ? (long long)lda : 1ll, cs = trans ? 1ll : (long long)lda;
-    int *sync = (int *)workspace(c, 2 * sizeof(int));
-    hipError_t e = hipMemsetAsync(sync, 0, 2 * sizeof(int), st);
+    int *sync = (int *)workspace(c, 4 * sizeof(int));
+    hipError_t e = hipMemsetAsync(sync, 0, 4 * sizeof(int), st);
     if (e != hipSuccess) return e;
 #define TV_ARGS n, a, rs, cs, x, (long long)incx, rev, unit, round_mode, sync, st
     if (fpe == 0) return trsv_variant<0, false>(TV_ARGS);

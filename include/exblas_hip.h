@@ -121,6 +121,10 @@ int exblas_exgemv_dev(char transa, int m, int n, double alpha, const double *d_a
 #define EXBLAS_UNSUPPORTED (-1)
 int exblas_extrsv_dev(char uplo, char transa, char diag, int n, const double *d_a, int lda, double *d_x,
                       int incx, int fpe, int early_exit, void *stream);
+/* Diagnostics: how many rows of the most recent exact ExTRSV on this device were rounded by the integer
+ * (superaccumulator) path instead of the register expansion -- near-ties, heavy cancellation, huge/tiny/non-finite
+ * values.  Synchronises the device; valid until the next exgemv/exgemm/extrsv call; -1 when unknown. */
+int exblas_extrsv_last_slow_rows(void);
 /* ExGEMM on device pointers, row-major (ExGEMM.Launcher.hpp; kernel gemm, ExGEMM.Superacc.cl:200-283). */
 int exblas_exgemm_dev(char transa, char transb, int m, int n, int k, double alpha,
                       const double *d_a, int lda, const double *d_b, int ldb, double beta,

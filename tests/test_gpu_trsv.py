@@ -153,3 +153,66 @@ def test_extrsv_device_pointer_api(ex, oracle):
         assert (_bits(dx.cpu().numpy()) == _bits(want)).all()
     dx = torch.from_numpy(b.copy()).cuda()
     assert ex.extrsv_dev("U", "N", "N", n, da, n, dx, 12) == -1
+
+
+def test_extrsv_ties_take_the_integer_path(ex, oracle):
+    """rows whose exact value is a rounding tie, or within 2^-106 of one: the register fast path cannot decide them
+    and must hand them to the superaccumulator; bits still equal the oracle's"""
+    lib = ex.load_library()
+    n = 96
+    m = np.zeros((n, n))                      # logical lower-triangular, unit-free: a_ii = 1
+    np.fill_diagonal(m, 1.0)
+    b = np.ones(n)
+    m[1:, 0] = -2.0 ** -53                    # T_i = 1 + 2^-53 * x_0: a tie, rounds to even (1.0)
+    m[2::3, 1] = -2.0 ** -106                 # ... pushed just above the tie: 1 + 2^-52
+    m[3::3, 1] = 2.0 ** -106                  # ... just below: 1.0
+    m[40:, 0] = 2.0 ** -54                    # T = 1 - 2^-54: tie below a power of two, rounds to 1.0
+    a = np.ascontiguousarray(m.T).reshape(-1)  # column-major
+    rc, want = oracle.extrsv("L", "N", "N", n, a, n, b, 0)
+    if oracle.mpfr() is not None:
+        assert (_bits(oracle.mpfr_extrsv("L", "N", "N", n, a, n, b, True)) == _bits(want)).all()
+    assert len(set(want.tolist())) >= 2
+    for fpe, ee in ((0, False), (4, False), (8, True)):
+        x = b.copy()
+        ex.extrsv("L", "N", "N", n, a, n, 0, x, 1, 0, fpe, ee)
+        assert (_bits(x) == _bits(want)).all(), (fpe, ee, np.nonzero(x != want)[0][:8])
+        assert lib.exblas_extrsv_last_slow_rows() >= n // 2
+
+
+def test_extrsv_scaled_rows_and_columns(ex, oracle):
+    """power-of-two row scalings up to 2^+-300 and column scalings up to 2^+-40: every magnitude of numerator,
+    denominator and quotient the division shortcut (and its fallback to '/') can meet; the well-conditioned core
+    keeps almost every row on the register fast path"""
+    lib = ex.load_library()
+    n = 2048
+    rng = np.random.default_rng(12)
+    for uplo in "LU":
+        a, b = tri_system(oracle, uplo, n, 41, dominant=True)
+        m = a.reshape(n, n).T.copy()          # logical
+        rs = 2.0 ** rng.integers(-300, 301, n)
+        cs = 2.0 ** rng.integers(-40, 41, n)
+        rs[::97] = 2.0 ** rng.integers(-500, 501, rs[::97].size)   # some rows beyond the shortcut's exponent window
+        m = m * rs[:, None] * cs[None, :]
+        bb = b * rs
+        aa = np.ascontiguousarray(m.T).reshape(-1)
+        rc, want = oracle.extrsv(uplo, "N", "N", n, aa, n, bb, 0)
+        assert np.isfinite(want).all()
+        for fpe, ee in ((0, False), (6, True)):
+            x = bb.copy()
+            ex.extrsv(uplo, "N", "N", n, aa, n, 0, x, 1, 0, fpe, ee)
+            assert (_bits(x) == _bits(want)).all(), (uplo, fpe, ee, np.nonzero(_bits(x) != _bits(want))[0][:8])
+            assert lib.exblas_extrsv_last_slow_rows() < n // 4
+
+
+def test_standalone_cpp_extrsv_caller(ex):
+    """reference-style C++ program (the flow of tests/test.extrsv.gpu.cpp, its CTest arguments
+    blas2/CMakeLists.txt:73-80) linked only against libexblas.so"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["make", "-C", os.path.join(root, "tests", "cpp")], check=True, capture_output=True)
+    for argv in (["U", "N", "N", "256"], ["U", "N", "N", "256", "10", "0"], ["L", "N", "N", "256", "10", "0"],
+                 ["L", "T", "U", "300", "6", "0"]):
+        r = subprocess.run([os.path.join(root, "tests", "cpp", "test_extrsv_gpu"), *argv], capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0 and "TestPassed; ALL OK!" in r.stdout, (argv, r.stdout[-2000:], r.stderr[-2000:])

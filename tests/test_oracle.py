@@ -172,3 +172,42 @@ def test_baseline_config1_plumbing(oracle):
             assert same_double(oracle.round_limbs(lr), want)
             r, l = oracle.exsum(a, fpe, ee, limbs=True)
             assert (l == l0).all() and same_double(r, want)
+
+
+def test_trsv_oracle_vs_mpfr_and_fraction(oracle):
+    """ExTRSV restatement: every variant equals the MPFR solve with the reference kernels' two roundings (exact
+    sum -> double, then fp64 division) bit for bit; a small case is also checked against Python Fractions; and the
+    reference test's own criterion (test.extrsv.gpu.cpp:27-92,:141: inf-norm distance to the single-rounding MPFR
+    solve <= 1e-13) holds.  No compiled reference exists for this routine (OpenCL only): MPFR is the pin."""
+    from fractions import Fraction
+    if oracle.mpfr() is None:
+        pytest.skip("no MPFR")
+    for uplo in "LU":
+        for trans in "NT":
+            for n in (1, 2, 17, 96):
+                a = oracle.gen("fpuniform_signed", n * n, 300 + n, 12, 3)
+                b = oracle.gen("fpuniform_signed", n, 301 + n, 12, 3)
+                want = oracle.mpfr_extrsv(uplo, trans, "N", n, a, n, b, True)
+                for fpe, ee in ((0, False), (2, False), (3, False), (5, False), (8, False), (4, True), (6, True),
+                                (8, True)):
+                    rc, x = oracle.extrsv(uplo, trans, "N", n, a, n, b, fpe, ee)
+                    assert rc == 0 and (x.view(np.int64) == want.view(np.int64)).all(), (uplo, trans, n, fpe, ee)
+                one = oracle.mpfr_extrsv(uplo, trans, "N", n, a, n, b, False)
+                if n <= 17:   # beyond that random triangular systems are too ill-conditioned for the 1e-13 criterion
+                    assert np.max(np.abs(want - one)) <= 1e-13 * np.max(np.abs(one))
+    # exact rational check of the definition, n = 6 lower
+    n = 6
+    a = oracle.gen("fpuniform_signed", n * n, 9, 20, 5)
+    b = oracle.gen("fpuniform_signed", n, 10, 20, 5)
+    rc, x = oracle.extrsv("L", "N", "N", n, a, n, b, 0)
+    xs = []
+    for i in range(n):
+        t = Fraction(float(b[i])) - sum(Fraction(float(a[j * n + i])) * Fraction(xs[j]) for j in range(i))
+        # correctly rounded double of the rational t: float(Fraction) rounds to nearest even
+        xs.append(float(t) / float(a[i * n + i]))
+    assert (np.array(xs).view(np.int64) == x.view(np.int64)).all()
+    assert oracle.extrsv("L", "N", "N", n, a, n, b, 12)[0] == -1          # iterative-refinement variants
+    rc, u = oracle.extrsv("U", "N", "U", n, a, n, b, 0)                   # unit diagonal: stored diagonal ignored
+    a2 = a.copy().reshape(n, n)
+    np.fill_diagonal(a2, 1.0)
+    assert (oracle.extrsv("U", "N", "N", n, a2.reshape(-1), n, b, 0)[1].view(np.int64) == u.view(np.int64)).all()

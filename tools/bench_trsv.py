@@ -21,8 +21,24 @@ def system(n, uplo):
 
 
 def main():
-    sizes = [int(s) for s in sys.argv[1:]] or [4096, 32768]
-    ex.load_library().exblas_hip_init(-1)
+    quick = "--sweep" in sys.argv
+    sizes = [int(s) for s in sys.argv[1:] if not s.startswith("--")] or [4096, 32768]
+    lib = ex.load_library()
+    lib.exblas_hip_init(-1)
+    if quick:   # latency model: t = t_launch + rows * t_row + blocks * t_block
+        for n in (64, 128, 256, 512, 1024, 2048, 4096, 8192):
+            a, b = system(n, "L")
+            ts = []
+            for it in range(6):
+                x = b.clone()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                ex.extrsv_dev("L", "N", "N", n, a, n, x, 4, False)
+                e1.record()
+                torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1))
+            print(f"sweep n={n}: {min(ts[1:]) * 1e3:.1f} us  slow rows {lib.exblas_extrsv_last_slow_rows()}", flush=True)
+        return
     for n in sizes:
         for uplo, trans in (("L", "N"), ("U", "N"), ("L", "T")):
             a, b = system(n, uplo)
