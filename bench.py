@@ -223,7 +223,23 @@ def bench_blas23(ex, torch, world, rank):
     ms = timeit(lambda: ex.exgemv_dev("N", m, n, 1.0, a, m, x, 1.0, y, 8, True), 10)
     gv = {"workload": "ExGEMV 'N' m=n=32768 fp64 column-major alpha=beta=1, fpe=8 early_exit, per GPU", "ms": ms,
           "bytes": 8.0 * (m * n + n + 2 * m)}
-    del a
+    # ExTRSV on the same matrix storage (lower triangle of a, made diagonally dominant): latency-bound, replicas
+    # for N > 1 (the substitution does not shard)
+    d = ex.gen_dev("fpuniform", n, 16, 1.0, 17.0)        # diagonal entries in [2^16, 2^17): dominates 32767 entries < 1
+    a.view(n, n).diagonal().copy_(d)
+    b = ex.gen_dev("fpuniform_signed", n, 17, 10.0, 0.0)
+    xs = torch.empty_like(b)
+
+    def solve():
+        xs.copy_(b)
+        ex.extrsv_dev("L", "N", "N", n, a, n, xs, 8, True)
+    ms = timeit(solve, 3)
+    tv = {"workload": "ExTRSV 'L','N','N' n=32768 fp64 column-major, fpe=8 early_exit, per GPU", "ms": ms,
+          "us_per_row": ms * 1e3 / n, "n2_per_s_G": n * float(n) / (ms * 1e-3) / 1e9,
+          "bound": "latency: one dependency chain of n rounded divisions (DESIGN.md 5a)",
+          "rows_on_integer_path": ex.load_library().exblas_extrsv_last_slow_rows(),
+          "finite": bool(torch.isfinite(xs).all())}
+    del a, d, b, xs
     N = 8192
     r0, r1 = ex.row_block(N, rank, world)
     A = ex.gen_dev("fpuniform", N * N, 14, 10.0, 0.0, first=r0 * N, count=(r1 - r0) * N)
@@ -233,7 +249,7 @@ def bench_blas23(ex, torch, world, rank):
     gm = {"workload": f"ExGEMM n=8192 fp64 row-major alpha=1, rows sharded over {world} GPU(s), "
                       "MFMA-F64 slice path", "ms": ms, "flop_total": 2.0 * N * N * N,
           "slices": ex.load_library().exblas_last_gemm_slices()}
-    return {"exgemv": gv, "exgemm": gm}
+    return {"exgemv": gv, "exgemm": gm, "extrsv": tv}
 
 
 def main():
@@ -374,6 +390,7 @@ def main():
                               "frac": mf / (78.6 * world), "traffic": None, "kernel": "k_gemm_mfma"}
             out["exgemv"] = gv
             out["exgemm"] = gm
+            out["extrsv"] = blas23["extrsv"]
         if world == 1 and not args.no_cpu_baseline:
             host = [t.cpu().numpy() for t in tensors]
             base, ok = cpu_baseline(args.op, host, args.fpe, ee, result.canon)

@@ -283,7 +283,10 @@ __device__ __forceinline__ long long wave_shr1(long long v)
     hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, true);
     return (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo);
 }
-__device__ __forceinline__ unsigned lane_bcast(unsigned v, int l) { return (unsigned)__builtin_amdgcn_readlane((int)v, l); }
+__device__ __forceinline__ unsigned lane_bcast(unsigned v, int l)
+{
+    return (unsigned)__builtin_amdgcn_readlane((int)v, l);
+}
 __device__ __forceinline__ long long lane_bcast(long long v, int l)
 {
     const unsigned lo = lane_bcast((unsigned)v, l), hi = lane_bcast((unsigned)(v >> 32), l);
