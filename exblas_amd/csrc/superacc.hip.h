@@ -268,7 +268,7 @@ __device__ inline void finish_record(long long *v, unsigned flags, long long *ou
 
 // ---------------------------------------------------------------------------------------------
 // The final step inside ONE wavefront, registers only: lane l holds limb l (v0) and, for l < 4, limb 64+l (v1).
-// Carries travel one lane per pass with __shfl_up (wave-wide vote ends the loop), the leading / lowest non-zero
+// Carries travel one lane per pass (DPP wave_shr:1; a wave-wide vote ends the loop), the leading / lowest non-zero
 // digits come from __ballot masks, canonical limbs are cut with per-lane __shfl gathers.  No LDS, no barrier.
 // All 64 lanes must call it.  Same bits as the single-thread finish_record above (the scalar ExGEMM kernel still
 // uses that one; the parity tests run both against the oracle).
