@@ -57,7 +57,7 @@ __device__ __forceinline__ void st_coherent(double *p, double v)
     __hip_atomic_store((long long *)p, __double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-constexpr int DG_M = 4;    // expansion levels per row in the diagonal phase
+constexpr int DG_M = 3;    // expansion levels per row in the diagonal phase
 constexpr int DG_K = 6;    // limbs below a row's leading limb that row_to_fpe moves into the expansion
 
 // x enters levels FROM..DG_M-1 of g; what is left after the last level goes to the row's integer accumulator
@@ -241,12 +241,12 @@ __global__ void __launch_bounds__(TB *TW) k_trsv(int n, const double *__restrict
                 s = two_sum(g[k], s, e);
                 err += fabs(e);
             }
+            // |total - s| <= err + B =: eb (rounded up into y).  s is the correctly rounded total when y is below half
+            // the distance to s's neighbour on either side -- tested by letting the adder round: |s| + y and |s| - y
+            // must both give |s| back.  (y == 0 passes for any s, zero and subnormals included; B == inf, NaN never do.)
             const double as = fabs(s);
-            const double gap = as - __longlong_as_double(__double_as_longlong(as) - 1);  // to the neighbour towards 0
-            const unsigned be = expo_field(s);
-            const double eb = err + B;
-            // eb == 0: the total IS s (any magnitude); otherwise s must be an ordinary normal number
-            const bool ok = (eb * 1.0000001 < 0.5 * gap && be > 128u && be < BIG_EXPO) || (eb == 0.0 && be < BIG_EXPO);
+            const double y = (err + B) * 1.0000001;
+            const bool ok = (as + y == as) && (as - y == as);
             double v;
             if (__builtin_expect((int)((__ballot(ok) >> i) & 1ull), 1)) {
                 v = lane_bcast(s, i) + 0.0;  // + 0.0: an exact zero total is +0 like the integer path's
