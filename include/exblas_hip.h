@@ -4,8 +4,8 @@
  *
  * Two layers:
  *  (1) host-pointer entry points with exactly the argument meaning of the reference's public C++
- *      API (include/blas1.hpp:48,74; blas2.hpp:95; blas3.hpp:56) -- what its tests and examples call;
- *      the C++ overloads themselves (exsum/exdot/exgemv/exgemm, global namespace) are declared in
+ *      API (include/blas1.hpp:48,74; blas2.hpp:57,95; blas3.hpp:56) -- what its tests and examples call;
+ *      the C++ overloads themselves (exsum/exdot/extrsv/exgemv/exgemm, global namespace) are declared in
  *      include/blas1.hpp, blas2.hpp, blas3.hpp of this repository and exported by the same library.
  *  (2) device-pointer, stream-ordered entry points underneath: what the reference's launcher layer
  *      (extern "C" initEx* / Ex* / closeEx* on cl_mem, src/gpu/blas/blas1/ExSUM.Launcher.hpp,
@@ -16,6 +16,13 @@
  * fpe < 0 or a HIP failure prints to stderr and exit(EXIT_FAILURE)s (cpu:ExSUM.cpp:25-28,
  * gpu:ExSUM.cpp:111-115); Ng <= 0 returns 0.0 (ExDOT.cpp:70-71).  The *_dev functions return a
  * hipError_t-compatible int instead of exiting (0 = success).
+ *
+ * Concurrency: the host-pointer layer may be called from any number of threads (calls on one device are
+ * serialised; the reference's GPU library is not re-entrant at all, ExSUM.Launcher.cpp:16-36).  The *_dev layer
+ * keeps ONE set of group accumulators and ONE workspace per device (two accumulator slots, see
+ * exblas_set_accumulator_slot): its calls may come from any thread, but the work they enqueue must be ordered on
+ * the device -- one stream, or streams chained by events -- exactly like kernels sharing a scratch buffer.
+ * The first call of each kind allocates (hipMalloc): make it before capturing a stream into a hipGraph.
  *
  * Rounding: EXBLAS_ROUND=exact (default; correctly rounded = the MPFR oracle of
  * tests/test.exsum.gpu.cpp:23-38) or EXBLAS_ROUND=reference (bug-compatible with
