@@ -669,6 +669,33 @@ int orc_extrsv(char uplo, char transa, char diag, int n, const double *a, int ld
     const int unit = (diag == 'U' || diag == 'u');
     /* A**T of a lower matrix is upper and vice versa: the dependency order follows the logical shape */
     const int fwd = lower != trans;
+    if (nfpe == 0 && !trans && n > 512) {
+        /* Same arithmetic, column by column (right-looking): one superaccumulator per row, and every finished
+         * x_i is applied to all remaining rows at once.  Exact accumulation does not depend on the order, so
+         * the result is the row-by-row one below; this form walks A along its columns (contiguous) and lets
+         * OpenMP share the rows, which is what makes n = 40000 checkable in seconds. */
+        orc_superacc *sa = (orc_superacc *)malloc((size_t)n * sizeof(orc_superacc));
+        if (!sa) return -2;
+        for (int i = 0; i < n; ++i) orc_sa_init(&sa[i]);
+        for (int s = 0; s < n; ++s) {
+            const int i = fwd ? s : n - 1 - s;
+            double *xi = &x[offsetx + (int64_t)i * incx];
+            orc_sa_accumulate(&sa[i], *xi);
+            double v = (round_mode == ORC_ROUND_REFERENCE) ? orc_sa_round_reference(&sa[i]) : orc_sa_round_exact(&sa[i]);
+            if (!unit) v = v / a[offseta + (int64_t)i * lda + i];
+            *xi = v;
+            const int r0 = fwd ? i + 1 : 0, r1 = fwd ? n : i;
+            const double *col = &a[offseta + (int64_t)lda * i];
+#pragma omp parallel for schedule(static) if (r1 - r0 > 2048)
+            for (int r = r0; r < r1; ++r) {
+                double e, p = orc_two_prod(col[r], -v, &e);
+                orc_sa_accumulate(&sa[r], p);
+                if (e != 0.0) orc_sa_accumulate(&sa[r], e);
+            }
+        }
+        free(sa);
+        return 0;
+    }
     for (int s = 0; s < n; ++s) {
         const int i = fwd ? s : n - 1 - s;
         const int j0 = fwd ? 0 : i + 1, j1 = fwd ? i : n;

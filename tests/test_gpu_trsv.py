@@ -216,3 +216,22 @@ def test_standalone_cpp_extrsv_caller(ex):
         r = subprocess.run([os.path.join(root, "tests", "cpp", "test_extrsv_gpu"), *argv], capture_output=True,
                            text=True, timeout=600)
         assert r.returncode == 0 and "TestPassed; ALL OK!" in r.stdout, (argv, r.stdout[-2000:], r.stderr[-2000:])
+
+
+def test_extrsv_full_size_more_blocks_than_resident(ex, oracle):
+    """n = 40000: 625 block-rows, more than the 512 workgroups the chip holds at once, so the ticket order of
+    the block-rows (a workgroup only waits for workgroups that already run) is what keeps the solve alive; and the
+    BASELINE-scale parity check of the whole chain: every component equal to the oracle's (a sequential CPU solve of
+    8e8 exact multiply-adds, ~15 s)."""
+    n = 40000
+    k = int(np.ceil(np.log2(n))) + 1
+    a = oracle.gen("fpuniform_signed", n * n, 123, 6, -k)       # column-major; the upper triangle is never read
+    a[::n + 1] = oracle.gen("fpuniform_signed", n, 124, 1, 0)   # diagonal in +-[0.5, 1): dominant
+    b = oracle.gen("fpuniform_signed", n, 125, 10, 0)
+    x = b.copy()
+    assert ex.extrsv("L", "N", "N", n, a, n, 0, x, 1, 0, 8, True) == 0
+    slow = ex.load_library().exblas_extrsv_last_slow_rows()
+    assert 0 <= slow < n // 100
+    rc, want = oracle.extrsv("L", "N", "N", n, a, n, b, 0)
+    assert rc == 0 and np.isfinite(want).all()
+    assert (_bits(x) == _bits(want)).all(), np.nonzero(_bits(x) != _bits(want))[0][:8]

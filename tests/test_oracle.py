@@ -195,6 +195,17 @@ def test_trsv_oracle_vs_mpfr_and_fraction(oracle):
                 one = oracle.mpfr_extrsv(uplo, trans, "N", n, a, n, b, False)
                 if n <= 17:   # beyond that random triangular systems are too ill-conditioned for the 1e-13 criterion
                     assert np.max(np.abs(want - one)) <= 1e-13 * np.max(np.abs(one))
+    # above n = 512 the superaccumulator-only variant runs column by column (OpenMP over rows): same bits as the
+    # row-by-row expansion variants
+    n = 600
+    for uplo in "LU":
+        a = oracle.gen("fpuniform_signed", n * n, 21, 6, -11)
+        a[::n + 1] = oracle.gen("fpuniform_signed", n, 22, 1, 0)
+        b = oracle.gen("fpuniform_signed", n, 23, 10, 0)
+        c0 = oracle.extrsv(uplo, "N", "N", n, a, n, b, 0)[1]
+        c4 = oracle.extrsv(uplo, "N", "N", n, a, n, b, 4, True)[1]
+        assert (c0.view(np.int64) == c4.view(np.int64)).all()
+        assert (c0.view(np.int64) == oracle.mpfr_extrsv(uplo, "N", "N", n, a, n, b, True).view(np.int64)).all()
     # exact rational check of the definition, n = 6 lower
     n = 6
     a = oracle.gen("fpuniform_signed", n * n, 9, 20, 5)
