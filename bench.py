@@ -101,8 +101,17 @@ def timed_steps(ex, torch, dist, op, tensors, fpe, ee, steps, warmup, world, rec
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
 
+    # clock ramp-up: untimed steps for about prewarm_ms.  With several ranks the number of steps (= collectives) must
+    # be the same everywhere, so the ranks vote after every batch whether to go on.
     t_pre = time.perf_counter()
-    while (time.perf_counter() - t_pre) * 1e3 < prewarm_ms:
+    while prewarm_ms > 0:
+        go = (time.perf_counter() - t_pre) * 1e3 < prewarm_ms
+        if use_dist:
+            flag = torch.tensor([1 if go else 0], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            go = bool(flag.item())
+        if not go:
+            break
         for _ in range(20):
             one_step()
         drain()
@@ -265,8 +274,15 @@ def main():
     if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # EXBLAS_BENCH_BACKEND=gloo rehearses the N > 1 control flow on a box with fewer GPUs than ranks (ranks then
+        # share the devices round-robin); the measured configuration is always nccl (= RCCL), one GPU per rank
+        backend = os.environ.get("EXBLAS_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            torch.cuda.set_device(local_rank % torch.cuda.device_count())
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
