@@ -33,8 +33,11 @@ if ks:
 
 
 def short(name):
-    for k in ("k_exsum", "k_exdot", "k_stream_read", "k_finalize", "k_gen", "k_gemv", "k_gemm"):
-        if k in name:
+    # longest names first: k_stream_read2 must not be averaged into k_stream_read (it reads twice the bytes)
+    for k in ("k_stream_read2", "k_stream_read", "k_exsum_segmented", "k_exsum", "k_exdot", "k_finalize", "k_gen",
+              "k_gemv_finish", "k_gemvN_fpe", "k_gemvN_sa", "k_gemvT", "k_gemm_mfma", "k_gemm", "k_trsv", "k_dtrsv",
+              "k_scan"):
+        if k + "<" in name or k + "(" in name:
             return k
     return None
 
