@@ -235,3 +235,15 @@ def test_extrsv_full_size_more_blocks_than_resident(ex, oracle):
     rc, want = oracle.extrsv("L", "N", "N", n, a, n, b, 0)
     assert rc == 0 and np.isfinite(want).all()
     assert (_bits(x) == _bits(want)).all(), np.nonzero(_bits(x) != _bits(want))[0][:8]
+
+
+def test_extrsv_randomized_soak(ex):
+    """tools/stress_trsv.py: 120 random (n, uplo, trans, diag, lda, incx, variant) cases, well-conditioned and wild
+    (overflowing) systems, each run three times: bits equal to the oracle and equal run to run"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_trsv.py"), "120", "3"], capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0 and "0 mismatches" in r.stdout, (r.stdout[-3000:], r.stderr[-2000:])
