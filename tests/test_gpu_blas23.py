@@ -233,3 +233,15 @@ def test_exgemm_mfma_fallbacks(ex, oracle):
     a = base_a.copy().reshape(m, k); a[3, :] = 0.0; a[10, ::2] = -0.0
     b = base_b.copy().reshape(k, n); b[:, 7] = 0.0
     run(a.reshape(-1), b.reshape(-1), True)                # zero row / zero column / signed zeros: fast path
+
+
+def test_gemv_gemm_randomized_soak(ex):
+    """tools/stress_blas23.py: 180 random shapes / transposes / alpha, beta / leading dimensions / strides / offsets /
+    variants / data families for ExGEMV and ExGEMM (scalar and MFMA paths): bits equal to the oracle"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_blas23.py"), "180", "11"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "0 mismatches" in r.stdout, (r.stdout[-3000:], r.stderr[-2000:])
