@@ -19,9 +19,13 @@
 //   * per row the running sum lives in a register expansion per (wave, lane) and spills to the row's private
 //     integer accumulator in LDS (68 limbs, pitch 69 words: a wave adding to the same limb of 64 rows, the common
 //     case, touches 64 different banks);
-//   * the diagonal block is solved by ONE wave, registers + LDS only: per row a wave-parallel carry resolution and
-//     rounding of the row's 68 limbs (finish_wave<false>: shuffles and ballots, no barrier), one fp64 division,
-//     and one TwoProd per remaining row.
+//   * the diagonal block is solved by ONE wave.  A lone wave retires about one instruction per 7-9 cycles, so the
+//     chain step is priced in instructions: each row's exact value is kept as a 3-level TwoSum expansion in the
+//     lane's registers (plus whatever the integer accumulator still holds, with a bound on it); a new x costs every
+//     later row one TwoProd and two short cascades, and at its turn a row is folded to one double whose correct
+//     rounding is certified by letting the adder round (|s| +- bound must return |s|).  Only rows that fail the
+//     certificate -- ties, cancellation to the noise floor, huge / subnormal / non-finite values -- go through the
+//     wave-parallel integer rounding (finish_wave<false>).  About 110 instructions per row instead of 400.
 // Cross-workgroup traffic: x values are written and read with agent-scope relaxed atomics (they bypass the
 // non-coherent cache levels), the "blocks done" counter with release / acquire.
 #include "exblas_internal.h"
