@@ -19,8 +19,8 @@
 //   * per row the running sum lives in a register expansion per (wave, lane) and spills to the row's private
 //     integer accumulator in LDS (68 limbs, pitch 69 words: a wave adding to the same limb of 64 rows, the common
 //     case, touches 64 different banks);
-//   * the diagonal block is solved by ONE wave.  A lone wave retires an instruction about every 4 ns (measured), so the
-//     chain step is priced in instructions: each row's exact value is kept as a 3-level TwoSum expansion in the
+//   * the diagonal block is solved by ONE wave.  A lone wave retires one fp64 instruction per 8 shader clocks (3.35 ns,
+//     tools/micro/lone_wave.hip), dependent or not, so the chain step is priced in instructions: each row's exact value is kept as a 3-level TwoSum expansion in the
 //     lane's registers (plus whatever the integer accumulator still holds, with a bound on it); a new x costs every
 //     later row one TwoProd and two short cascades, and at its turn a row is folded to one double whose correct
 //     rounding is certified by letting the adder round (|s| +- bound must return |s|).  Only rows that fail the
@@ -223,7 +223,7 @@ __global__ void __launch_bounds__(TB *TW) k_trsv(int n, const double *__restrict
             }
         }
     } else {
-        // Exact rounding, register fast path.  A lone wave retires roughly one instruction per 4 ns, so the
+        // Exact rounding, register fast path.  A lone wave retires one fp64 instruction per 8 clocks, so the
         // chain is priced in INSTRUCTIONS per row; the integer route (2 x lds_add, LDS round trip, wave-wide
         // carry resolution and rounding, ~400 instructions) is replaced by a DG_M-level expansion per lane:
         //     value of row j  =  g_j[0] + ... + g_j[DG_M-1]  +  (row j of the LDS accumulator),   |LDS part| <= B_j
