@@ -44,11 +44,13 @@ static_assert(TCW == 16, "the tile loop below is written for 2 x 8 columns per w
 struct RowSink {
     long long *row;
     unsigned *flagp;
+    int *touched;  // workgroup-wide: "some integer accumulator of this block holds something"
     __device__ __forceinline__ void add(double x)
     {
         unsigned f = 0;
         lds_add<1>(row, x, f);
         if (f) atomicOr(flagp, f);  // Inf / NaN: rare
+        *touched = 1;
     }
 };
 
@@ -62,6 +64,7 @@ __device__ __forceinline__ void st_coherent(double *p, double v)
 }
 
 constexpr int DG_M = 3;    // expansion levels per row in the diagonal phase
+constexpr int DG_PUB = 4;  // expansion levels a tile-phase wave hands over as doubles (deeper ones go through the accumulator)
 constexpr int DG_K = 6;    // limbs below a row's leading limb that row_to_fpe moves into the expansion
 
 // x enters levels FROM..DG_M-1 of g; what is left after the last level goes to the row's integer accumulator
@@ -152,9 +155,13 @@ __global__ void __launch_bounds__(TB *TW) k_trsv(int n, const double *__restrict
     __shared__ long long acc[TB * TPITCH];
     __shared__ double dg[TB * TB];  // diagonal block, dg[c * TB + r], strictly-lower part
     __shared__ unsigned rflags[TB];
-    __shared__ int s_row, s_known[2];
+    __shared__ double fpub[TW][DG_PUB][TB];  // leading expansion levels of the tile phase, wave -> diagonal wave
+    __shared__ int s_row, s_known[2], s_touched;
     const int tid = (int)threadIdx.x, lane = tid & 63, w = tid >> 6;
-    if (tid == 0) s_row = atomicAdd(&sync[0], 1);
+    if (tid == 0) {
+        s_row = atomicAdd(&sync[0], 1);
+        s_touched = 0;
+    }
     for (int i = tid; i < TB * TPITCH; i += TB * TW) acc[i] = 0;
     if (tid < TB) rflags[tid] = 0;
     __syncthreads();
@@ -179,7 +186,7 @@ __global__ void __launch_bounds__(TB *TW) k_trsv(int n, const double *__restrict
     double f[N > 0 ? N : 1];
 #pragma unroll
     for (int i = 0; i < (N > 0 ? N : 1); ++i) f[i] = 0.0;
-    RowSink sink{acc + lane * TPITCH, &rflags[lane]};
+    RowSink sink{acc + lane * TPITCH, &rflags[lane], &s_touched};
     int bypass = 0, known = 0, parity = 0;
 
     for (int C = 0; C < R; ++C) {
@@ -199,8 +206,20 @@ __global__ void __launch_bounds__(TB *TW) k_trsv(int n, const double *__restrict
             fpe_absorb_prod_adaptive<N, EE, 8>(f, p, e, sink, bypass);
         }
     }
-    fpe_flush_sink<N>(f, sink);
-    if (w == 0 && active) sink.add(rhs);
+    if (mode != 0) {
+        fpe_flush_sink<N>(f, sink);
+        if (w == 0 && active) sink.add(rhs);
+    } else {
+        // hand the expansions over as doubles (the diagonal wave adds them to its own expansion): no detour through
+        // the integer accumulator unless a level beyond DG_PUB holds something
+#pragma unroll
+        for (int k = 0; k < DG_PUB; ++k) fpub[w][k][lane] = (N > k) ? f[k < N ? k : 0] : 0.0;
+        if constexpr (N > DG_PUB) {
+#pragma unroll
+            for (int k = DG_PUB; k < N; ++k)
+                if (f[k] != 0.0) sink.add(f[k]);
+        }
+    }
     __syncthreads();
     if (w != 0) return;
 
@@ -234,7 +253,28 @@ __global__ void __launch_bounds__(TB *TW) k_trsv(int n, const double *__restrict
         // rounded total (one double, no tie possible).  Otherwise -- near-ties, cancellation down to the noise,
         // huge / tiny / non-finite values -- the row is flushed to LDS and rounded by the integer path.
         double g[DG_M], B = 0.0;
-        row_to_fpe(acc + lane * TPITCH, rflags[lane], g, B, sink);
+        if (s_touched) {  // uniform; rare for the expansion variants on data they can hold
+            row_to_fpe(acc + lane * TPITCH, rflags[lane], g, B, sink);
+        } else {
+#pragma unroll
+            for (int k = 0; k < DG_M; ++k) g[k] = 0.0;
+        }
+        // leading levels first: the larger terms settle in the upper levels of g
+#pragma unroll
+        for (int k = 0; k < DG_PUB; ++k)
+#pragma unroll
+            for (int ww = 0; ww < TW; ++ww) {
+                const double v = fpub[ww][k][lane];
+                if (__any(v != 0.0)) fpe_push<0>(g, B, v, sink);
+            }
+        if (active) {
+            if (__builtin_expect(expo_field(rhs) >= BIG_EXPO, 0)) {  // huge or non-finite right-hand side: integer side
+                sink.add(rhs);
+                B = __builtin_inf();
+            } else {
+                fpe_push<0>(g, B, rhs, sink);
+            }
+        }
         double acol = dg[lane];
         for (int i = 0; i < rows; ++i) {
             // ---- row i's turn (every lane evaluates its own row; lane i's answer is taken) ----

@@ -26,7 +26,7 @@ def main():
     lib = ex.load_library()
     lib.exblas_hip_init(-1)
     if quick:   # latency model: t = t_launch + rows * t_row + blocks * t_block
-        for n in (64, 128, 256, 512, 1024, 2048, 4096, 8192):
+        for n in (8, 16, 32, 48, 64, 128, 256, 512, 1024, 2048, 4096, 8192):
             a, b = system(n, "L")
             ts = []
             for it in range(6):
