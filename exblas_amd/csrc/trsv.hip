@@ -26,8 +26,9 @@
 //     rounding is certified by letting the adder round (|s| +- bound must return |s|).  Only rows that fail the
 //     certificate -- ties, cancellation to the noise floor, huge / subnormal / non-finite values -- go through the
 //     wave-parallel integer rounding (finish_wave<false>).  About 110 instructions per row instead of 400.
-// Cross-workgroup traffic: x values are written and read with agent-scope relaxed atomics (they bypass the
-// non-coherent cache levels), the "blocks done" counter with release / acquire.
+// Cross-workgroup traffic: finished x values are posted to a mailbox (one double per row, preset to a reserved NaN
+// pattern) with agent-scope relaxed atomic stores and fetched with agent-scope atomic loads, which bypass the
+// non-coherent cache levels: the value is its own ready flag -- no fence, counter or barrier on the hand-off.
 #include "exblas_internal.h"
 #include "fpe.hip.h"
 
@@ -54,17 +55,8 @@ struct RowSink {
     }
 };
 
-__device__ __forceinline__ double ld_coherent(const double *p)
-{
-    return __longlong_as_double(__hip_atomic_load((const long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
-__device__ __forceinline__ void st_coherent(double *p, double v)
-{
-    __hip_atomic_store((long long *)p, __double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 constexpr int DG_M = 3;    // expansion levels per row in the diagonal phase
-constexpr int DG_PUB = 4;  // expansion levels a tile-phase wave hands over as doubles (deeper ones go through the accumulator)
+constexpr int DG_PUB = 4;  // non-empty expansion levels a tile-phase wave hands over as doubles (more: through the accumulator)
 constexpr int DG_K = 6;    // limbs below a row's leading limb that row_to_fpe moves into the expansion
 
 // x enters levels FROM..DG_M-1 of g; what is left after the last level goes to the row's integer accumulator
@@ -126,37 +118,43 @@ __device__ inline void row_to_fpe(long long *row, unsigned rowflags, double (&g)
     }
 }
 
-// Blocks until `done` (number of finished block-rows) exceeds C.  Thread 0 polls, everybody learns the value read
-// through LDS, so that already-finished blocks cost no further global access.  `known` is workgroup-uniform.
-__device__ __forceinline__ void wait_block(const int *done, int C, int &known, int *s_known, int &parity)
+// Solution values travel between workgroups through a mailbox xq[logical row], preset to a NaN pattern no result
+// can carry (the writer maps that one pattern to the canonical NaN): the value is its own "ready" flag, so a
+// consumer needs ONE coherent load round trip per tile and no fence, counter or workgroup barrier.
+constexpr long long XQ_EMPTY = -1ll;  // 0xFFFFFFFFFFFFFFFF
+__device__ __forceinline__ void post_x(double *xq, double v)
 {
-    if (C < known) return;
-    if (threadIdx.x == 0) {
-        int v;
-        while ((v = __hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) <= C)
-            __builtin_amdgcn_s_sleep(1);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // pairs with the publisher's release
-        s_known[parity] = v;
+    long long b = __double_as_longlong(v);
+    if (b == XQ_EMPTY) b = 0x7ff8000000000000ll;
+    __hip_atomic_store((long long *)xq, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// lanes with `want` set fetch *q, polling until it has been posted; wave-uniform loop
+__device__ __forceinline__ double fetch_x(const double *q, bool want)
+{
+    long long b = 0;
+    for (;;) {
+        if (want) b = __hip_atomic_load((const long long *)q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!__any(want && b == XQ_EMPTY)) break;
+        __builtin_amdgcn_s_sleep(1);  // every workgroup behind the front polls the same few lines: keep it light
     }
-    __syncthreads();
-    known = s_known[parity];
-    parity ^= 1;  // a thread can lag at most one wait behind thread 0: two slots are enough
+    return __longlong_as_double(b);
 }
 
 // ---------------------------------------------------------------------------------------------
 // the exact solve.  Logical indices run in substitution order; phys() maps them to storage (reversed for
 // backward substitution).  Element (row r, column c) of the logical matrix is a[phys(r)*rs + phys(c)*cs].
-// sync[0]: block-row ticket, sync[1]: block-rows done, sync[2]: rows rounded by the integer path (statistics).
+// sync[0]: block-row ticket, sync[2]: rows rounded by the integer path (statistics).
 // ---------------------------------------------------------------------------------------------
 template <int N, bool EE>
 __global__ void __launch_bounds__(TB *TW) k_trsv(int n, const double *__restrict__ a, long long rs, long long cs,
-                                                 double *x, long long incx, int rev, int unit, int mode, int *sync)
+                                                 double *x, long long incx, int rev, int unit, int mode, int *sync,
+                                                 double *xq)
 {
     __shared__ long long acc[TB * TPITCH];
     __shared__ double dg[TB * TB];  // diagonal block, dg[c * TB + r], strictly-lower part
     __shared__ unsigned rflags[TB];
     __shared__ double fpub[TW][DG_PUB][TB];  // leading expansion levels of the tile phase, wave -> diagonal wave
-    __shared__ int s_row, s_known[2], s_touched;
+    __shared__ int s_row, s_touched;
     const int tid = (int)threadIdx.x, lane = tid & 63, w = tid >> 6;
     if (tid == 0) {
         s_row = atomicAdd(&sync[0], 1);
@@ -187,7 +185,7 @@ __global__ void __launch_bounds__(TB *TW) k_trsv(int n, const double *__restrict
 #pragma unroll
     for (int i = 0; i < (N > 0 ? N : 1); ++i) f[i] = 0.0;
     RowSink sink{acc + lane * TPITCH, &rflags[lane], &s_touched};
-    int bypass = 0, known = 0, parity = 0;
+    int bypass = 0;
 
     for (int C = 0; C < R; ++C) {
         const int c0 = C * TB + w * TCW;
@@ -195,9 +193,7 @@ __global__ void __launch_bounds__(TB *TW) k_trsv(int n, const double *__restrict
 #pragma unroll
         for (int u = 0; u < TCW; ++u)
             av[u] = active ? __builtin_nontemporal_load(arow + phys(c0 + u) * cs) : 0.0;
-        wait_block(&sync[1], C, known, s_known, parity);
-        double xl = 0.0;
-        if (lane < TCW) xl = ld_coherent(x + phys(c0 + lane) * incx);
+        const double xl = fetch_x(xq + c0 + lane, lane < TCW);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             double p[8], e[8];
@@ -211,14 +207,22 @@ __global__ void __launch_bounds__(TB *TW) k_trsv(int n, const double *__restrict
         if (w == 0 && active) sink.add(rhs);
     } else {
         // hand the expansions over as doubles (the diagonal wave adds them to its own expansion): no detour through
-        // the integer accumulator unless a level beyond DG_PUB holds something
+        // the integer accumulator unless more than DG_PUB levels hold something
+        // (the early-exit variants keep products in levels 0-1 and their error terms in levels N-3.. : the levels in
+        // use, not the first DG_PUB, are the ones that travel; a fifth non-empty level goes through the accumulator)
+        int slot = 0;  // wave-uniform
 #pragma unroll
-        for (int k = 0; k < DG_PUB; ++k) fpub[w][k][lane] = (N > k) ? f[k < N ? k : 0] : 0.0;
-        if constexpr (N > DG_PUB) {
-#pragma unroll
-            for (int k = DG_PUB; k < N; ++k)
-                if (f[k] != 0.0) sink.add(f[k]);
+        for (int k = 0; k < N; ++k) {
+            if (__any(f[k] != 0.0)) {
+                if (slot < DG_PUB) {
+                    fpub[w][slot][lane] = f[k];
+                    ++slot;
+                } else if (f[k] != 0.0) {
+                    sink.add(f[k]);
+                }
+            }
         }
+        for (; slot < DG_PUB; ++slot) fpub[w][slot][lane] = 0.0;
     }
     __syncthreads();
     if (w != 0) return;
@@ -324,9 +328,10 @@ __global__ void __launch_bounds__(TB *TW) k_trsv(int n, const double *__restrict
             }
         }
     }
-    if (active) st_coherent(x + rp * incx, xs);
-    __threadfence();  // x is visible device-wide before the counter moves
-    if (lane == 0) __hip_atomic_store(&sync[1], R + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (active) {
+        post_x(xq + r, xs);
+        x[rp * incx] = xs;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -334,11 +339,11 @@ __global__ void __launch_bounds__(TB *TW) k_trsv(int n, const double *__restrict
 // the partial sums of the 4 waves are combined in a fixed order.
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(TB *TW) k_dtrsv(int n, const double *__restrict__ a, long long rs, long long cs,
-                                                  double *x, long long incx, int rev, int unit, int *sync)
+                                                  double *x, long long incx, int rev, int unit, int *sync, double *xq)
 {
     __shared__ double dg[TB * TB];
     __shared__ double part[TW][TB];
-    __shared__ int s_row, s_known[2];
+    __shared__ int s_row;
     const int tid = (int)threadIdx.x, lane = tid & 63, w = tid >> 6;
     if (tid == 0) s_row = atomicAdd(&sync[0], 1);
     __syncthreads();
@@ -354,16 +359,13 @@ __global__ void __launch_bounds__(TB *TW) k_dtrsv(int n, const double *__restric
         dg[cc * TB + lane] = v;
     }
     double s = 0.0;
-    int known = 0, parity = 0;
     for (int C = 0; C < R; ++C) {
         const int c0 = C * TB + w * TCW;
         double av[TCW];
 #pragma unroll
         for (int u = 0; u < TCW; ++u)
             av[u] = active ? __builtin_nontemporal_load(arow + phys(c0 + u) * cs) : 0.0;
-        wait_block(&sync[1], C, known, s_known, parity);
-        double xl = 0.0;
-        if (lane < TCW) xl = ld_coherent(x + phys(c0 + lane) * incx);
+        const double xl = fetch_x(xq + c0 + lane, lane < TCW);
 #pragma unroll
         for (int u = 0; u < TCW; ++u) s -= av[u] * lane_bcast(xl, u);
     }
@@ -380,17 +382,18 @@ __global__ void __launch_bounds__(TB *TW) k_dtrsv(int n, const double *__restric
         const double v = __shfl(t, i);
         if (lane > i && active) t -= dg[i * TB + lane] * v;
     }
-    if (active) st_coherent(x + rp * incx, t);
-    __threadfence();
-    if (lane == 0) __hip_atomic_store(&sync[1], R + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (active) {
+        post_x(xq + r, t);
+        x[rp * incx] = t;
+    }
 }
 
 template <int N, bool EE>
 hipError_t trsv_variant(int n, const double *a, long long rs, long long cs, double *x, long long incx, int rev, int unit,
-                        int mode, int *sync, hipStream_t st)
+                        int mode, int *sync, double *xq, hipStream_t st)
 {
     hipLaunchKernelGGL((k_trsv<N, EE>), dim3((n + TB - 1) / TB), dim3(TB * TW), 0, st, n, a, rs, cs, x, incx, rev, unit,
-                       mode, sync);
+                       mode, sync, xq);
     return hipGetLastError();
 }
 
@@ -407,14 +410,17 @@ hipError_t extrsv_dispatch(Ctx &c, char uplo, char transa, char diag, int n, con
     const int unit = (diag == 'U' || diag == 'u') ? 1 : 0;
     const int rev = (lower != trans) ? 0 : 1;  // A**T of a lower matrix is upper: backward substitution
     const long long rs = trans ? (long long)lda : 1ll, cs = trans ? 1ll : (long long)lda;
-    int *sync = (int *)workspace(c, 4 * sizeof(int));
-    hipError_t e = hipMemsetAsync(sync, 0, 4 * sizeof(int), st);
+    // workspace: 16 ints (ticket, statistics) then the mailbox of n doubles
+    int *sync = (int *)workspace(c, 64 + (size_t)n * sizeof(double));
+    double *xq = (double *)((char *)sync + 64);
+    hipError_t e = hipMemsetAsync(sync, 0, 64, st);
     if (e != hipSuccess) return e;
-#define TV_ARGS n, a, rs, cs, x, (long long)incx, rev, unit, round_mode, sync, st
+    if ((e = hipMemsetAsync(xq, 0xff, (size_t)n * sizeof(double), st)) != hipSuccess) return e;
+#define TV_ARGS n, a, rs, cs, x, (long long)incx, rev, unit, round_mode, sync, xq, st
     if (fpe == 0) return trsv_variant<0, false>(TV_ARGS);
     if (fpe == 1) {
         hipLaunchKernelGGL(k_dtrsv, dim3((n + TB - 1) / TB), dim3(TB * TW), 0, st, n, a, rs, cs, x, (long long)incx, rev,
-                           unit, sync);
+                           unit, sync, xq);
         return hipGetLastError();
     }
     if (early_exit) {
