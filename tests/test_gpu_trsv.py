@@ -247,3 +247,32 @@ def test_extrsv_randomized_soak(ex):
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_trsv.py"), "120", "3"], capture_output=True,
                        text=True, timeout=900)
     assert r.returncode == 0 and "0 mismatches" in r.stdout, (r.stdout[-3000:], r.stderr[-2000:])
+
+
+def test_extrsv_and_gemv_in_a_hip_graph(ex, oracle):
+    """exgemv_dev and extrsv_dev are stream-ordered launches (plus two memset nodes for the solve): captured once,
+    replayed three times -- solve L x = A v + y repeatedly, bits equal to the oracle's every time"""
+    import torch
+    n = 700
+    a, b = tri_system(oracle, "L", n, 333, dominant=True)
+    a = np.nan_to_num(a, nan=0.0)            # exgemv reads the whole square: the upper triangle must be finite
+    v = oracle.gen("fpuniform_signed", n, 334, 10, 0)
+    da, dv = torch.from_numpy(a).cuda(), torch.from_numpy(v).cuda()
+    dy0 = torch.from_numpy(b).cuda()
+    dx = dy0.clone()
+    ex.exgemv_dev("N", n, n, 1.0, da, n, dv, 1.0, dx, 8, True)     # lazy allocations happen outside the capture
+    ex.extrsv_dev("L", "N", "N", n, da, n, dx, 8, True)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            dx.copy_(dy0)
+            ex.exgemv_dev("N", n, n, 1.0, da, n, dv, 1.0, dx, 8, True)
+            ex.extrsv_dev("L", "N", "N", n, da, n, dx, 8, True)
+    want = oracle.extrsv("L", "N", "N", n, a, n, oracle.exgemv("N", n, n, 1.0, a, n, v, 1.0, b, 0), 0)[1]
+    for _ in range(3):
+        dx.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert (_bits(dx.cpu().numpy()) == _bits(want)).all()
