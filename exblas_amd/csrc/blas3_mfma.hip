@@ -151,29 +151,27 @@ __global__ void __launch_bounds__(256) k_scan_finish(int nvec, int *vmax, const 
 }
 
 // ---------------------------------------------------------------------------------------------
-// slicing: |x| / 2^(ea - BETA*S) as an integer (exact by the scan's guarantee), cut into S chunks of BETA bits
+// slicing: x = sum_p out[p] * 2^(ea - BETA*(p+1)) with integer digits out[p], exactly (the scan guarantees that x is
+// a multiple of 2^(ea - BETA*S) and |x| < 2^ea).  Digits are taken with the classic error-free extraction
+// q = (x + c) - c, c = 1.5 * 2^(52 + w): x rounded to the nearest multiple of 2^w, exact, and x - q is exact too --
+// four fp64 instructions per digit instead of a 128-bit variable shift.  Round-to-nearest makes the digits
+// balanced: |out[0]| <= 2^BETA, |out[p > 0]| <= 2^(BETA-1), so a group sum over KP = 512 products stays below 2^53
+// (worst group: 4 pairs, each with at least one lower digit: 4 * 512 * 2^(2*BETA-1) = 2^52).
 // ---------------------------------------------------------------------------------------------
 template <int S>
 __device__ __forceinline__ void slice(double x, int ea, double (&out)[S])
 {
-    const unsigned long long u = (unsigned long long)__double_as_longlong(x);
-    const unsigned be = (unsigned)(u >> 52) & 0x7ffu;
-    if (be == 0) {
-#pragma unroll
-        for (int p = 0; p < S; ++p) out[p] = 0.0;
-        return;
-    }
-    const unsigned long long mant = (u & 0x000fffffffffffffull) | 0x0010000000000000ull;
-    const int e = (int)be - 1023;
-    // X = mant * 2^t, t = (e - 52) - (ea - BETA*S); X < 2^(BETA*S) <= 2^84
-    const int t = e - 52 - ea + MF_BETA * S;
-    unsigned __int128 X = (unsigned __int128)mant;
-    if (t >= 0) X <<= t; else X >>= (-t);  // right shifts drop only zero bits (scan: need <= BETA*S)
-    const double sgn = (u >> 63) ? -1.0 : 1.0;
 #pragma unroll
     for (int p = 0; p < S; ++p) {
-        const unsigned chunk = (unsigned)(X >> (MF_BETA * (S - 1 - p))) & ((1u << MF_BETA) - 1u);
-        out[p] = sgn * (double)chunk;  // exact small integer
+        const int w = ea - MF_BETA * (p + 1);  // weight exponent of digit p
+        if (p < S - 1) {
+            const double c = ldexp(1.5, 52 + w);
+            const double q = (x + c) - c;
+            x -= q;
+            out[p] = ldexp(q, -w);
+        } else {
+            out[p] = ldexp(x, -w);
+        }
     }
 }
 
