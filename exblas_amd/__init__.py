@@ -39,9 +39,13 @@ _lib = None
 
 def load_library():
     """Load (building first if sources are newer) lib/libexblas.so.  Raises if it cannot be had."""
-    global _lib
+    global _lib, LIB_PATH
     if _lib is not None:
         return _lib
+    alt = os.environ.get("EXBLAS_AMD_LIB")  # A/B of an alternative build (tools/): load exactly this file
+    if alt:
+        LIB_PATH = os.path.abspath(alt)
+        _build.stale = lambda: False
     if not os.path.exists(LIB_PATH) or (_build.stale() and _build.hipcc() and os.path.exists(_build.hipcc())):
         try:
             _build.build()

@@ -5,8 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import exblas_amd as ex
 if len(sys.argv) > 1 and sys.argv[1] != "default":
-    ex.LIB_PATH = os.path.abspath(sys.argv[1])
-    ex._build.stale = lambda: False
+    os.environ["EXBLAS_AMD_LIB"] = sys.argv[1]   # honoured by exblas_amd.load_library()
 ex.load_library().exblas_hip_init(-1)
 print("lib:", ex.LIB_PATH, flush=True)
 
