@@ -230,9 +230,9 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_exdot(const double *__restrict__
                 rb[u] = ld2<NT>(vb + base + u * BLOCK);
             }
         }
-        while (t < ntiles) {
-            const long long tn = t + gridDim.x;
-            if constexpr (HALVES) {
+        if constexpr (HALVES) {
+            while (t < ntiles) {
+                const long long tn = t + gridDim.x;
                 // two half-tiles: the registers of a half are re-loaded (next tile) as soon as its products are
                 // formed, so only U products + U errors are live at a time (fewer VGPRs -> more waves per SIMD)
                 constexpr int H = U / 2;
@@ -254,24 +254,40 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_exdot(const double *__restrict__
                     }
                     fpe_absorb_prod_adaptive<N, EE, 2 * H>(fpe, x, e, sink, bypass);
                 }
-            } else {
+                t = tn;
+            }
+        } else if (t < ntiles) {
+            // Two explicit register sets, filled alternately; the loads are unconditional (past the end they
+            // fetch the last tile again), so the compiler has no reason to copy one set into the other each
+            // trip (16 v_mov_b64 per tile with a conditional reload) and both sets stay in flight.
+            d2_t rc[U], rd[U];
+            auto fill = [&](long long tile, d2_t (&pa)[U], d2_t (&pb)[U]) {
+                const long long base = (tile < ntiles ? tile : ntiles - 1) * TILE + threadIdx.x;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    pa[u] = ld2<NT>(va + base + u * BLOCK);
+                    pb[u] = ld2<NT>(vb + base + u * BLOCK);
+                }
+            };
+            auto absorb = [&](d2_t (&pa)[U], d2_t (&pb)[U]) {
                 double x[2 * U], e[2 * U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    x[2 * u] = two_prod(ra[u].x, rb[u].x, e[2 * u]);
-                    x[2 * u + 1] = two_prod(ra[u].y, rb[u].y, e[2 * u + 1]);
-                }
-                if (tn < ntiles) {
-                    const long long base = tn * TILE + threadIdx.x;
-#pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        ra[u] = ld2<NT>(va + base + u * BLOCK);
-                        rb[u] = ld2<NT>(vb + base + u * BLOCK);
-                    }
+                    x[2 * u] = two_prod(pa[u].x, pb[u].x, e[2 * u]);
+                    x[2 * u + 1] = two_prod(pa[u].y, pb[u].y, e[2 * u + 1]);
                 }
                 fpe_absorb_prod_adaptive<N, EE, 2 * U>(fpe, x, e, sink, bypass);
+            };
+            for (;;) {
+                fill(t + gridDim.x, rc, rd);
+                absorb(ra, rb);
+                t += gridDim.x;
+                if (t >= ntiles) break;
+                fill(t + gridDim.x, ra, rb);
+                absorb(rc, rd);
+                t += gridDim.x;
+                if (t >= ntiles) break;
             }
-            t = tn;
         }
     }
     for (long long i = ntiles * TILE + (long long)blockIdx.x * BLOCK + threadIdx.x; i < nv;
