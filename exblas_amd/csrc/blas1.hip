@@ -114,27 +114,35 @@ __global__ void __launch_bounds__(BLOCK) k_exsum(const double *__restrict__ a, l
             tstride = 1;
             tend = min(ntiles, t + per);
         }
-        d2_t r[U];
         if (t < tend) {
-            const d2_t *p = v + t * TILE + threadIdx.x;
-#pragma unroll
-            for (int u = 0; u < U; ++u) r[u] = ld2<NT>(p + u * BLOCK);
-        }
-        while (t < tend) {
-            double x[2 * U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                x[2 * u] = r[u].x;
-                x[2 * u + 1] = r[u].y;
-            }
-            const long long tn = t + tstride;
-            if (tn < tend) {
-                const d2_t *p = v + tn * TILE + threadIdx.x;
+            // two explicit register sets, filled alternately with unconditional loads (past the end: the last tile
+            // again) -- see k_exdot: no per-trip copies between the sets, both in flight
+            d2_t r0[U], r1[U];
+            auto fill = [&](long long tile, d2_t (&r)[U]) {
+                const d2_t *p = v + (tile < tend ? tile : tend - 1) * TILE + threadIdx.x;
 #pragma unroll
                 for (int u = 0; u < U; ++u) r[u] = ld2<NT>(p + u * BLOCK);
+            };
+            auto absorb = [&](d2_t (&r)[U]) {
+                double x[2 * U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    x[2 * u] = r[u].x;
+                    x[2 * u + 1] = r[u].y;
+                }
+                fpe_absorb_adaptive<N, EE, 2 * U, LdsSink<COPIES>, ZM>(fpe, x, sinkm, bypass);
+            };
+            fill(t, r0);
+            for (;;) {
+                fill(t + tstride, r1);
+                absorb(r0);
+                t += tstride;
+                if (t >= tend) break;
+                fill(t + tstride, r0);
+                absorb(r1);
+                t += tstride;
+                if (t >= tend) break;
             }
-            fpe_absorb_adaptive<N, EE, 2 * U, LdsSink<COPIES>, ZM>(fpe, x, sinkm, bypass);
-            t = tn;
         }
     }
     // remainder vectors, grid-strided one double2 at a time
