@@ -274,6 +274,10 @@ def main():
     if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if force_dist and world == 1:  # stand-alone rehearsal without a launcher: a group of one
+            os.environ.setdefault("MASTER_PORT", "29517")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         # EXBLAS_BENCH_BACKEND=gloo rehearses the N > 1 control flow on a box with fewer GPUs than ranks (ranks then
         # share the devices round-robin); the measured configuration is always nccl (= RCCL), one GPU per rank
         backend = os.environ.get("EXBLAS_BENCH_BACKEND", "nccl")
