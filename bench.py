@@ -128,9 +128,9 @@ def timed_steps(ex, torch, dist, op, tensors, fpe, ee, steps, warmup, world, rec
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(steps):
-        # N > 1: every event is one more packet between the streaming kernels, next to those of the collective; the
-        # kernel time is then sampled on every fourth step
-        if use_dist and i % 4:
+        # every event is one more packet in the queue between two streaming kernels (~3 us each): the kernel time is
+        # sampled on every fourth step instead of bracketing all of them
+        if i % 4 and steps >= 8:
             one_step()
         else:
             one_step(*ev[i])
@@ -140,7 +140,7 @@ def timed_steps(ex, torch, dist, op, tensors, fpe, ee, steps, warmup, world, rec
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    timed = [p for i, p in enumerate(ev) if not (use_dist and i % 4)]
+    timed = [p for i, p in enumerate(ev) if not (i % 4 and steps >= 8)]
     kms = sum(a.elapsed_time(b) for a, b in timed) / max(len(timed), 1)
     if state["last"] is not rec:
         rec.copy_(state["last"])
