@@ -222,23 +222,37 @@ __global__ void __launch_bounds__(GV_BLOCK) k_gemvT(int m, double alpha, const d
         // workgroup starts its sweep at a different tile (and wraps) so that concurrent columns spread over the
         // channels instead of marching through them in lockstep.
         const long long t0 = stagger ? (j * 37) % (ntiles > 0 ? ntiles : 1) : 0;
-        for (long long tt = 0; tt < ntiles; ++tt) {
-            long long t = tt + t0;
-            if (t >= ntiles) t -= ntiles;
-            const long long base = t * tile + tid;
-            d2_t ra[U], rx[U];
+        if (ntiles > 0) {
+            // two register sets filled alternately with unconditional loads (see k_exdot in blas1.hip)
+            d2_t ra[U], rx[U], rb[U], ry[U];
+            auto fill = [&](long long tt, d2_t (&qa)[U], d2_t (&qx)[U]) {
+                long long t = (tt < ntiles ? tt : ntiles - 1) + t0;
+                if (t >= ntiles) t -= ntiles;
+                const long long base = t * tile + tid;
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                ra[u] = ld2<true>(va + base + u * GV_BLOCK);
-                rx[u] = vx[base + u * GV_BLOCK];  // x is re-read by every workgroup: keep it cacheable
-            }
-            double p[2 * U], e[2 * U];
+                for (int u = 0; u < U; ++u) {
+                    qa[u] = ld2<true>(va + base + u * GV_BLOCK);
+                    qx[u] = vx[base + u * GV_BLOCK];  // x is re-read by every workgroup: keep it cacheable
+                }
+            };
+            auto absorb = [&](d2_t (&qa)[U], d2_t (&qx)[U]) {
+                double p[2 * U], e[2 * U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                p[2 * u] = two_prod(ra[u].x, alpha * rx[u].x, e[2 * u]);
-                p[2 * u + 1] = two_prod(ra[u].y, alpha * rx[u].y, e[2 * u + 1]);
+                for (int u = 0; u < U; ++u) {
+                    p[2 * u] = two_prod(qa[u].x, alpha * qx[u].x, e[2 * u]);
+                    p[2 * u + 1] = two_prod(qa[u].y, alpha * qx[u].y, e[2 * u + 1]);
+                }
+                fpe_absorb_prod_adaptive<N, EE, 2 * U>(f, p, e, sink, bypass);
+            };
+            fill(0, ra, rx);
+            for (long long tt = 0;;) {
+                fill(tt + 1, rb, ry);
+                absorb(ra, rx);
+                if (++tt >= ntiles) break;
+                fill(tt + 1, ra, rx);
+                absorb(rb, ry);
+                if (++tt >= ntiles) break;
             }
-            fpe_absorb_prod_adaptive<N, EE, 2 * U>(f, p, e, sink, bypass);
         }
         done = ntiles * tile * 2;
     }
