@@ -440,22 +440,31 @@ bool exgemm_try_mfma(Ctx &c, char transa, char transb, int m, int n, int k, doub
     const int s = sa > sb ? sa : sb;
     if (s > 4 || s < 1) return false;
     // k-blocks: (k / KP) * G * 2^53 must fit the 256-bit accumulator: 53 + BETA*(2S-2) + log2(k/KP * G) < 255
-#define MF_GO(S, RT, CT, WPS) \
-    launch_mfma<S, S, RT, CT, WPS>(ta, tb, m, n, k, alpha, a, lda, b, ldb, beta, cmat, ldc, EA, EB, st)
-    // wave tile RT x CT and waves/SIMD: chosen by A/B on MI355X (tools/bench_gemm.py); c.variant selects the others
-    switch (s) {
-    case 1: case 2:
-        if (c.variant == 1) MF_GO(2, 2, 2, 1); else MF_GO(2, 1, 2, 2);
-        break;
-    case 3:
-        if (c.variant == 1) MF_GO(3, 2, 2, 1);
-        else if (c.variant == 2) MF_GO(3, 1, 1, 4);
-        else if (c.variant == 3) MF_GO(3, 1, 1, 3);
-        else MF_GO(3, 1, 2, 2);
-        break;
-    default:
-        if (c.variant == 2) MF_GO(4, 1, 1, 2); else MF_GO(4, 1, 2, 1);
-        break;
+#define MF_GO(SA_, SB_, RT, CT, WPS) \
+    launch_mfma<SA_, SB_, RT, CT, WPS>(ta, tb, m, n, k, alpha, a, lda, b, ldb, beta, cmat, ldc, EA, EB, st)
+    // wave tile RT x CT and waves/SIMD: chosen by A/B on MI355X (tools/bench_gemm.py); c.variant selects the others.
+    // Operands that need different digit counts get their own instantiation (SA x SB products per element pair
+    // instead of max^2) for the common mixed cases; the rest run with the larger count on both sides.
+    const int ua = sa < 2 ? 2 : sa, ub = sb < 2 ? 2 : sb;
+    if (c.variant == 0 && ua == 2 && ub == 3) {
+        MF_GO(2, 3, 1, 2, 2);
+    } else if (c.variant == 0 && ua == 3 && ub == 2) {
+        MF_GO(3, 2, 1, 2, 2);
+    } else {
+        switch (s) {
+        case 1: case 2:
+            if (c.variant == 1) MF_GO(2, 2, 2, 2, 1); else MF_GO(2, 2, 1, 2, 2);
+            break;
+        case 3:
+            if (c.variant == 1) MF_GO(3, 3, 2, 2, 1);
+            else if (c.variant == 2) MF_GO(3, 3, 1, 1, 4);
+            else if (c.variant == 3) MF_GO(3, 3, 1, 1, 3);
+            else MF_GO(3, 3, 1, 2, 2);
+            break;
+        default:
+            if (c.variant == 2) MF_GO(4, 4, 1, 1, 2); else MF_GO(4, 4, 1, 2, 1);
+            break;
+        }
     }
 #undef MF_GO
     c.last_gemm_slices = s < 2 ? 2 : s;

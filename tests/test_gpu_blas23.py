@@ -245,3 +245,20 @@ def test_gemv_gemm_randomized_soak(ex):
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_blas23.py"), "180", "11"],
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "0 mismatches" in r.stdout, (r.stdout[-3000:], r.stderr[-2000:])
+
+
+def test_exgemm_mfma_mixed_digit_counts(ex, oracle):
+    """operands that need different numbers of 21-bit digits (A: 16-bit integers times powers of two -> 2 digits,
+    B: full 53-bit mantissas over 2^10 -> 3) run the 2x3 / 3x2 instantiations: same bits as the oracle"""
+    lib = ex.load_library()
+    rng = np.random.default_rng(5)
+    m, n, k = 96, 130, 700
+    small = rng.integers(-30000, 30001, size=m * k).astype(np.float64) * 2.0 ** rng.integers(-3, 4, size=m * k)
+    full = oracle.gen("fpuniform_signed", k * n, 77, 10, 0)
+    c0 = oracle.gen("fpuniform_signed", m * n, 78, 10, 0)
+    for a, b, mm, nn in ((small, full, m, n), (full[:n * k], small[:k * m], n, m)):
+        want = oracle.exgemm("N", "N", mm, nn, k, 1.0, a, k, b, nn, 1.0, c0[:mm * nn], nn, 0)
+        c = c0[:mm * nn].copy()
+        ex.exgemm("N", "N", mm, nn, k, 1.0, a, k, b, nn, 1.0, c, nn, 8, True)
+        assert lib.exblas_last_gemm_slices() == 3
+        assert (_bits(c) == _bits(want)).all()
