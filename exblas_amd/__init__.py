@@ -31,8 +31,19 @@ C_ABI_SYMBOLS = [
     "exblas_exsum_accumulate_dev", "exblas_exdot_accumulate_dev", "exblas_finish_dev", "exblas_set_tuning",
     "exblas_set_gemm_path", "exblas_last_gemm_slices", "exblas_exsum_segmented_dev",
     "exblas_set_accumulator_slot", "exblas_stream_read2_dev", "exblas_extrsv_dev", "exblas_extrsv",
-    "exblas_extrsv_last_slow_rows",
+    "exblas_extrsv_last_slow_rows", "exblas_reserve_workspace", "exblas_release_retired_workspaces",
+    "exblas_comm_unique_id", "exblas_comm_init_rccl", "exblas_comm_adopt_rccl", "exblas_comm_init_host",
+    "exblas_comm_destroy", "exblas_comm_rank", "exblas_comm_size", "exblas_shard_range",
+    "exblas_exsum_allreduce_dev", "exblas_exdot_allreduce_dev", "exblas_allreduce_finish_dev",
+    "exblas_exgemv_sharded_dev", "exblas_exgemm_sharded_dev",
 ]
+
+# host-transport callback types of include/exblas_hip.h
+HOST_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int64), C.c_int64)
+HOST_BCAST_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int)
+HOST_ALLGATHERV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64))
+UNIQUE_ID_BYTES = 128
+COMM_ERROR = -2
 
 _lib = None
 
@@ -46,12 +57,18 @@ def load_library():
     if alt:
         LIB_PATH = os.path.abspath(alt)
         _build.stale = lambda: False
-    if not os.path.exists(LIB_PATH) or (_build.stale() and _build.hipcc() and os.path.exists(_build.hipcc())):
-        try:
-            _build.build()
-        except Exception as exc:  # noqa: BLE001
-            if not os.path.exists(LIB_PATH):
-                raise ImportError(f"exblas_amd: cannot build {LIB_PATH}: {exc}") from exc
+    if not os.path.exists(LIB_PATH) or _build.stale():
+        have_hipcc = bool(_build.hipcc()) and os.path.exists(_build.hipcc())
+        if have_hipcc:
+            # a failed rebuild is fatal: a library older than its sources must never be loaded in its place
+            try:
+                _build.build()
+            except Exception as exc:  # noqa: BLE001
+                raise ImportError(f"exblas_amd: building {LIB_PATH} failed ({exc}); refusing to load a stale "
+                                  "library") from exc
+        elif os.path.exists(LIB_PATH):
+            raise ImportError(f"exblas_amd: {LIB_PATH} is older than its sources and hipcc is not available to "
+                              "rebuild it")
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"exblas_amd: {LIB_PATH} is missing and hipcc is not available; "
                           "there is no CPU fallback")
@@ -93,6 +110,24 @@ def load_library():
     L.exblas_exdot.argtypes = [i32, vp, i32, i32, vp, i32, i32, i32, i32]
     L.exblas_exgemv.argtypes = [C.c_char, i32, i32, dbl, vp, i32, i32, vp, i32, i32, dbl, vp, i32, i32, i32, i32]
     L.exblas_exgemm.argtypes = [C.c_char, C.c_char, i32, i32, i32, dbl, vp, i32, vp, i32, dbl, vp, i32, i32, i32]
+    L.exblas_reserve_workspace.argtypes = [C.c_size_t]
+    L.exblas_comm_unique_id.argtypes = [vp]
+    L.exblas_comm_init_rccl.argtypes = [C.POINTER(vp), i32, i32, vp]
+    L.exblas_comm_adopt_rccl.argtypes = [C.POINTER(vp), vp, i32, i32]
+    L.exblas_comm_init_host.argtypes = [C.POINTER(vp), i32, i32, HOST_ALLREDUCE_FN, HOST_BCAST_FN, HOST_ALLGATHERV_FN,
+                                        vp]
+    L.exblas_comm_destroy.argtypes = [vp]
+    L.exblas_comm_rank.argtypes = [vp]
+    L.exblas_comm_size.argtypes = [vp]
+    L.exblas_shard_range.argtypes = [i64, i32, i32, C.POINTER(i64), C.POINTER(i64)]
+    L.exblas_shard_range.restype = None
+    L.exblas_exsum_allreduce_dev.argtypes = [vp, vp, i64, i64, i32, i32, vp, vp]
+    L.exblas_exdot_allreduce_dev.argtypes = [vp, vp, i64, vp, i64, i64, i32, i32, vp, vp]
+    L.exblas_allreduce_finish_dev.argtypes = [vp, vp, vp]
+    L.exblas_exgemv_sharded_dev.argtypes = [vp, C.c_char, i32, i32, dbl, vp, i32, vp, i32, i32, dbl, vp, i32, i32,
+                                            i32, vp]
+    L.exblas_exgemm_sharded_dev.argtypes = [vp, C.c_char, C.c_char, i32, i32, i32, dbl, vp, i32, vp, i32, i32, dbl,
+                                            vp, i32, i32, i32, vp]
     L.exblas_exsum_record.argtypes = [i32, vp, i32, i32, i32, i32, vp]
     L.exblas_exdot_record.argtypes = [i32, vp, i32, i32, vp, i32, i32, i32, i32, vp]
     _lib = L
@@ -359,5 +394,5 @@ def exgemm(transa, transb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, fpe, ea
                                         fpe, int(bool(early_exit)))
 
 
-from .dist import (exsum_allreduce, exdot_allreduce, allreduce_record, shard_range, row_block,  # noqa: E402,F401
-                   exgemv_rows, exgemm_rows)
+from .dist import (Comm, exsum_allreduce, exdot_allreduce, allreduce_finish, allreduce_record,  # noqa: E402,F401
+                   shard_range, row_block, exgemv_sharded, exgemm_sharded)

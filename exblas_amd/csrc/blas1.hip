@@ -554,11 +554,12 @@ hipError_t exsum_dispatch(Ctx &c, const double *a, long long n, long long inca, 
         case 5: return launch_exsum<5, false>(c, a, n, inca, st);
         case 6: return launch_exsum<6, false>(c, a, n, inca, st);
         case 7: return launch_exsum<7, false>(c, a, n, inca, st);
-        case 8: return launch_exsum<8, false>(c, a, n, inca, st);
-        default: break;
+        // fpe > 8 without early exit: the reference builds ExSUM.FPE.cl with -DNBFPE=fpe (gpu:ExSUM.cpp:80-81).  The
+        // exact sum does not depend on the expansion size, so the largest instantiation returns the same bits.
+        default: return launch_exsum<8, false>(c, a, n, inca, st);
         }
     }
-    *supported = false;  // the reference silently returns 0.0 (gpu:ExSUM.cpp:83)
+    *supported = false;  // early_exit with fpe > 8: the reference silently returns 0.0 (gpu:ExSUM.cpp:72-83)
     return hipSuccess;
 }
 
@@ -584,8 +585,7 @@ hipError_t exsum_segmented_dispatch(const double *values, const long long *offse
         case 5: SEG_GO(5, false); break;
         case 6: SEG_GO(6, false); break;
         case 7: SEG_GO(7, false); break;
-        case 8: SEG_GO(8, false); break;
-        default: return hipMemsetAsync(out, 0, sizeof(double) * nseg, st);
+        default: SEG_GO(8, false); break;  // fpe >= 8 (see exsum_dispatch)
         }
     }
 #undef SEG_GO
@@ -609,8 +609,7 @@ hipError_t exdot_dispatch(Ctx &c, const double *a, long long inca, const double 
         case 5: return launch_exdot<5, false>(c, a, inca, b, incb, n, st);
         case 6: return launch_exdot<6, false>(c, a, inca, b, incb, n, st);
         case 7: return launch_exdot<7, false>(c, a, inca, b, incb, n, st);
-        case 8: return launch_exdot<8, false>(c, a, inca, b, incb, n, st);
-        default: break;
+        default: return launch_exdot<8, false>(c, a, inca, b, incb, n, st);  // fpe >= 8 (ExDOT.cpp:93-94)
         }
     }
     *supported = false;

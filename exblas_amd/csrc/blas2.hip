@@ -333,10 +333,12 @@ static hipError_t gemvN_fpe(Ctx &c, int m, int n, double alpha, const double *a,
     KS = (n + kper - 1) / kper;
     const size_t ws_bytes = (size_t)m * SET_WORDS * sizeof(long long);
     const size_t part_bytes = (size_t)m * KS * N * sizeof(double);
-    char *base = (char *)workspace(c, ws_bytes + part_bytes);
+    hipError_t e;
+    char *base = (char *)workspace(c, ws_bytes + part_bytes, st, &e);
+    if (!base) return e;
     long long *ws = (long long *)base;
     double *part = (double *)(base + ws_bytes);
-    hipError_t e = hipMemsetAsync(ws, 0, ws_bytes, st);
+    e = hipMemsetAsync(ws, 0, ws_bytes, st);
     if (e != hipSuccess) return e;
     const bool vec = (m % 2 == 0) && (lda % 2 == 0) && (((uintptr_t)a) & 15u) == 0;
     dim3 grid(gx, KS);
@@ -368,8 +370,10 @@ static hipError_t gemvN_sa(Ctx &c, int m, int n, double alpha, const double *a, 
     const int kper = (n + KS - 1) / KS;
     KS = (n + kper - 1) / kper;
     const size_t ws_bytes = (size_t)m * SET_WORDS * sizeof(long long);
-    long long *ws = (long long *)workspace(c, ws_bytes);
-    hipError_t e = hipMemsetAsync(ws, 0, ws_bytes, st);
+    hipError_t e;
+    long long *ws = (long long *)workspace(c, ws_bytes, st, &e);
+    if (!ws) return e;
+    e = hipMemsetAsync(ws, 0, ws_bytes, st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_gemvN_sa, dim3(gx, KS), dim3(GV_BLOCK), 0, st, m, n, alpha, a, (long long)lda, x,
                        (long long)incx, kper, ws);
@@ -426,7 +430,7 @@ hipError_t exgemv_dispatch(Ctx &c, char transa, int m, int n, double alpha, cons
         if (fpe <= 4) return gemv_variant<4, true>(GV_ARGS);
         if (fpe <= 6) return gemv_variant<6, true>(GV_ARGS);
         if (fpe <= 8) return gemv_variant<8, true>(GV_ARGS);
-        return hipSuccess;
+        return hipSuccess;  // early_exit with fpe > 8: y untouched, the reference's silent return (ExGEMV.cpp:96-106)
     }
     switch (fpe) {
     case 2: return gemv_variant<2, false>(GV_ARGS);
@@ -435,8 +439,7 @@ hipError_t exgemv_dispatch(Ctx &c, char transa, int m, int n, double alpha, cons
     case 5: return gemv_variant<5, false>(GV_ARGS);
     case 6: return gemv_variant<6, false>(GV_ARGS);
     case 7: return gemv_variant<7, false>(GV_ARGS);
-    case 8: return gemv_variant<8, false>(GV_ARGS);
-    default: return hipSuccess;  // unsupported size: y untouched, like the reference's silent return
+    default: return gemv_variant<8, false>(GV_ARGS);  // fpe >= 8: ExGEMV.FPE.cl with NBFPE = fpe (ExGEMV.cpp:103-104), same bits
     }
 #undef GV_ARGS
 }

@@ -111,7 +111,7 @@ hipError_t exgemm_dispatch(Ctx &c, char transa, char transb, int m, int n, int k
     // MFMA-F64 fast path (blas3_mfma.hip): exact-rounding mode only; mode 0 = for the expansion variants when the
     // data qualifies, 1 = never, 2 = for every variant.  Falls through to the scalar kernel otherwise.
     if (round_mode == 0 && c.gemm_path != 1 && (fpe >= 3 || c.gemm_path == 2)) {
-        const bool variant_ok = !early_exit ? (fpe <= 8) : true;
+        const bool variant_ok = early_exit ? (fpe <= 8) : true;  // early_exit with fpe > 8 is a no-op (ExGEMM.cpp:88-99)
         if (variant_ok) {
             hipError_t e = hipSuccess;
             if (exgemm_try_mfma(c, transa, transb, m, n, k, alpha, a, lda, b, ldb, beta, cmat, ldc, st, &e)) return e;
@@ -131,8 +131,7 @@ hipError_t exgemm_dispatch(Ctx &c, char transa, char transb, int m, int n, int k
     case 5: return gemm_variant<5, false>(GM_ARGS);
     case 6: return gemm_variant<6, false>(GM_ARGS);
     case 7: return gemm_variant<7, false>(GM_ARGS);
-    case 8: return gemm_variant<8, false>(GM_ARGS);
-    default: return hipSuccess;
+    default: return gemm_variant<8, false>(GM_ARGS);  // fpe >= 8: ExGEMM.FPE.cl with NBFPE = fpe (ExGEMM.cpp:96-97), same bits
     }
 #undef GM_ARGS
 }

@@ -410,7 +410,8 @@ bool exgemm_try_mfma(Ctx &c, char transa, char transb, int m, int n, int k, doub
     c.last_gemm_slices = 0;
     if (k <= 0) return false;
     const int ta = (transa == 'T' || transa == 't'), tb = (transb == 'T' || transb == 't');
-    int *buf = (int *)workspace(c, sizeof(int) * (2 * ((size_t)m + n) + INFO_WORDS));
+    int *buf = (int *)workspace(c, sizeof(int) * (2 * ((size_t)m + n) + INFO_WORDS), st, err);
+    if (!buf) return true;
     int *info = buf, *EA = buf + INFO_WORDS, *EB = EA + m, *LA = EB + n, *LB = LA + m;
     const int init[INFO_WORDS] = {0, 0, 0, 100000, -100000, 0, 0, 0};
     if ((*err = hipMemcpyAsync(info, init, sizeof(init), hipMemcpyHostToDevice, st)) != hipSuccess) return true;

@@ -47,10 +47,26 @@ int round_mode()
 }
 
 static constexpr int MAX_DEV = 16;
-static Ctx g_ctx[MAX_DEV];
+static Ctx g_ctx[MAX_LAYERS][MAX_DEV];
 static std::mutex g_ctx_mu;
+static int g_last_layer[MAX_DEV];  // which layer ran the most recent exgemv / exgemm / extrsv (diagnostics only)
 
-Ctx &ctx(int device)
+// run f on every context of `device` that exists (tuning knobs are per device, not per layer)
+template <class F>
+static void for_each_layer(int device, F &&f)
+{
+    for (int l = 0; l < MAX_LAYERS; ++l)
+        if (g_ctx[l][device].device >= 0) f(g_ctx[l][device]);
+}
+
+static int current_device()
+{
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess) d = 0;
+    return d < MAX_DEV ? d : 0;
+}
+
+Ctx &ctx(int device, int layer)
 {
     if (device < 0) {
         hipError_t e = hipGetDevice(&device);
@@ -64,9 +80,11 @@ Ctx &ctx(int device)
         fprintf(stderr, "exblas(hip): device index %d out of range\n", device);
         exit(EXIT_FAILURE);
     }
-    Ctx &c = g_ctx[device];
+    if (layer < 0 || layer >= MAX_LAYERS) layer = 0;
+    Ctx &c = g_ctx[layer][device];
     std::lock_guard<std::mutex> lk(g_ctx_mu);
     if (c.device < 0) {
+        c.layer = layer;
         int prev = 0;
         EXB_CHECK(hipGetDevice(&prev));
         EXB_CHECK(hipSetDevice(device));
@@ -81,6 +99,11 @@ Ctx &ctx(int device)
         if (c.ngroups < 1) c.ngroups = 1;
         c.variant = env_int("EXBLAS_VARIANT", 0);
         c.gemm_path = env_int("EXBLAS_GEMM_PATH", 0);
+        if (layer > 0 && g_ctx[0][device].device >= 0) {  // knobs set through the API so far apply to every layer
+            const Ctx &z = g_ctx[0][device];
+            c.blocks_per_cu = z.blocks_per_cu; c.bpc_sum = z.bpc_sum; c.bpc_dot = z.bpc_dot; c.bpc_sa = z.bpc_sa;
+            c.ngroups = z.ngroups; c.variant = z.variant; c.gemm_path = z.gemm_path;
+        }
         EXB_CHECK(hipMalloc(&c.gacc_all, 2 * sizeof(long long) * NL * c.ngroups));
         EXB_CHECK(hipMemset(c.gacc_all, 0, 2 * sizeof(long long) * NL * c.ngroups));
         EXB_CHECK(hipMalloc(&c.gflags_all, 128));
@@ -109,12 +132,31 @@ void *stage_buf(Ctx &c, int slot, size_t bytes)
     return c.stage[slot];
 }
 
-void *workspace(Ctx &c, size_t bytes)
+void *workspace(Ctx &c, size_t bytes, hipStream_t st, hipError_t *err)
 {
+    *err = hipSuccess;
     if (bytes > c.ws_bytes) {
-        if (c.ws) EXB_CHECK(hipFree(c.ws));
-        EXB_CHECK(hipMalloc(&c.ws, bytes));
-        c.ws_bytes = bytes;
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (st && hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+            // hipMalloc is illegal during capture, and the graph would bake in a pointer that the next growth moves
+            *err = hipErrorStreamCaptureUnsupported;
+            return nullptr;
+        }
+        // the old block is parked, not freed: a graph captured earlier may still replay into it
+        if (c.ws) c.retired.push_back(c.ws);
+        size_t cap = bytes + (c.ws_bytes >> 1);  // geometric growth bounds what the parked blocks can add up to
+        void *p = nullptr;
+        hipError_t e = hipMalloc(&p, cap);
+        if (e != hipSuccess) {
+            cap = bytes;
+            e = hipMalloc(&p, cap);
+        }
+        if (e != hipSuccess) {
+            *err = e;
+            return nullptr;
+        }
+        c.ws = p;
+        c.ws_bytes = cap;
     }
     return c.ws;
 }
@@ -278,19 +320,21 @@ void exblas_set_round_mode(int mode) { g_round_mode = mode ? 1 : 0; }
 
 int exblas_set_tuning(int blocks_per_cu, int ngroups, int variant)
 {
-    Ctx &c = ctx(-1);
-    std::lock_guard<std::mutex> lk(c.mu);
-    if (blocks_per_cu > 0) c.blocks_per_cu = c.bpc_sum = c.bpc_dot = c.bpc_sa = blocks_per_cu;
-    if (ngroups > 0 && ngroups != c.ngroups) {
-        EXB_CHECK(hipDeviceSynchronize());
-        EXB_CHECK(hipFree(c.gacc_all));
-        c.ngroups = ngroups;
-        EXB_CHECK(hipMalloc(&c.gacc_all, 2 * sizeof(long long) * NL * c.ngroups));
-        EXB_CHECK(hipMemset(c.gacc_all, 0, 2 * sizeof(long long) * NL * c.ngroups));
-        c.gacc = c.gacc_all + (size_t)c.slot * NL * c.ngroups;
-        EXB_CHECK(hipDeviceSynchronize());
-    }
-    if (variant >= 0) c.variant = variant;
+    ctx(-1);
+    for_each_layer(current_device(), [&](Ctx &c) {
+        std::lock_guard<std::mutex> lk(c.mu);
+        if (blocks_per_cu > 0) c.blocks_per_cu = c.bpc_sum = c.bpc_dot = c.bpc_sa = blocks_per_cu;
+        if (ngroups > 0 && ngroups != c.ngroups) {
+            EXB_CHECK(hipDeviceSynchronize());
+            EXB_CHECK(hipFree(c.gacc_all));
+            c.ngroups = ngroups;
+            EXB_CHECK(hipMalloc(&c.gacc_all, 2 * sizeof(long long) * NL * c.ngroups));
+            EXB_CHECK(hipMemset(c.gacc_all, 0, 2 * sizeof(long long) * NL * c.ngroups));
+            c.gacc = c.gacc_all + (size_t)c.slot * NL * c.ngroups;
+            EXB_CHECK(hipDeviceSynchronize());
+        }
+        if (variant >= 0) c.variant = variant;
+    });
     return 0;
 }
 int exblas_get_round_mode(void) { return round_mode(); }
@@ -306,41 +350,87 @@ int exblas_set_accumulator_slot(int slot)
     return 0;
 }
 
-int exblas_last_gemm_slices(void) { return ctx(-1).last_gemm_slices; }
+int exblas_last_gemm_slices(void) { return ctx(-1, g_last_layer[current_device()]).last_gemm_slices; }
 
 void exblas_set_gemm_path(int mode)
 {
-    Ctx &c = ctx(-1);
+    ctx(-1);
+    for_each_layer(current_device(), [&](Ctx &c) {
+        std::lock_guard<std::mutex> lk(c.mu);
+        c.gemm_path = mode;
+    });
+}
+
+// ---- implementations on an explicit context (layer 0 for the *_dev entry points, a private one for host calls) ----
+static int exsum_accumulate_on(Ctx &c, const double *d_a, int64_t n, int64_t inca, int fpe, int early_exit,
+                               hipStream_t st)
+{
+    if (fpe < 0 || n > 0x7fffffffll) return (int)hipErrorInvalidValue;
     std::lock_guard<std::mutex> lk(c.mu);
-    c.gemm_path = mode;
+    bool ok = true;
+    // unsupported (fpe, early_exit) combination: nothing is launched, the accumulators stay zero -> 0.0
+    return n > 0 ? (int)exsum_dispatch(c, d_a, n, inca, fpe, early_exit, st, &ok) : 0;
+}
+
+static int exdot_accumulate_on(Ctx &c, const double *d_a, int64_t inca, const double *d_b, int64_t incb, int64_t n,
+                               int fpe, int early_exit, hipStream_t st)
+{
+    if (fpe < 0 || n > 0x7fffffffll) return (int)hipErrorInvalidValue;
+    std::lock_guard<std::mutex> lk(c.mu);
+    bool ok = true;
+    return n > 0 ? (int)exdot_dispatch(c, d_a, inca, d_b, incb, n, fpe, early_exit, st, &ok) : 0;
+}
+
+static int finish_on(Ctx &c, hipStream_t st, int64_t *d_out)
+{
+    std::lock_guard<std::mutex> lk(c.mu);
+    return (int)finalize_groups(c, st, (long long *)d_out);
+}
+
+static int exgemv_on(Ctx &c, char transa, int m, int n, double alpha, const double *d_a, int lda, const double *d_x,
+                     int incx, double beta, double *d_y, int incy, int fpe, int early_exit, hipStream_t st)
+{
+    if (fpe < 0) return (int)hipErrorInvalidValue;
+    std::lock_guard<std::mutex> lk(c.mu);
+    g_last_layer[c.device] = c.layer;
+    return (int)exgemv_dispatch(c, transa, m, n, alpha, d_a, lda, d_x, incx, beta, d_y, incy, fpe, early_exit,
+                                round_mode(), st);
+}
+
+static int extrsv_on(Ctx &c, char uplo, char transa, char diag, int n, const double *d_a, int lda, double *d_x,
+                     int incx, int fpe, int early_exit, hipStream_t st)
+{
+    if (fpe < 0) return (int)hipErrorInvalidValue;
+    if (fpe >= 9) return EXBLAS_UNSUPPORTED;
+    if (n > 0 && (lda < n || incx <= 0)) return (int)hipErrorInvalidValue;
+    std::lock_guard<std::mutex> lk(c.mu);
+    g_last_layer[c.device] = c.layer;
+    return (int)extrsv_dispatch(c, uplo, transa, diag, n, d_a, lda, d_x, incx, fpe, early_exit, round_mode(), st);
+}
+
+static int exgemm_on(Ctx &c, char transa, char transb, int m, int n, int k, double alpha, const double *d_a, int lda,
+                     const double *d_b, int ldb, double beta, double *d_c, int ldc, int fpe, int early_exit,
+                     hipStream_t st)
+{
+    if (fpe < 0) return (int)hipErrorInvalidValue;
+    std::lock_guard<std::mutex> lk(c.mu);
+    g_last_layer[c.device] = c.layer;
+    return (int)exgemm_dispatch(c, transa, transb, m, n, k, alpha, d_a, lda, d_b, ldb, beta, d_c, ldc, fpe,
+                                early_exit, round_mode(), st);
 }
 
 int exblas_exsum_accumulate_dev(const double *d_a, int64_t n, int64_t inca, int fpe, int early_exit, void *stream)
 {
-    if (fpe < 0 || n > 0x7fffffffll) return (int)hipErrorInvalidValue;
-    Ctx &c = ctx(-1);
-    std::lock_guard<std::mutex> lk(c.mu);
-    bool ok = true;
-    // unsupported (fpe, early_exit) combination: nothing is launched, the accumulators stay zero -> 0.0
-    return n > 0 ? (int)exsum_dispatch(c, d_a, n, inca, fpe, early_exit, (hipStream_t)stream, &ok) : 0;
+    return exsum_accumulate_on(ctx(-1), d_a, n, inca, fpe, early_exit, (hipStream_t)stream);
 }
 
 int exblas_exdot_accumulate_dev(const double *d_a, int64_t inca, const double *d_b, int64_t incb, int64_t n, int fpe,
                                 int early_exit, void *stream)
 {
-    if (fpe < 0 || n > 0x7fffffffll) return (int)hipErrorInvalidValue;
-    Ctx &c = ctx(-1);
-    std::lock_guard<std::mutex> lk(c.mu);
-    bool ok = true;
-    return n > 0 ? (int)exdot_dispatch(c, d_a, inca, d_b, incb, n, fpe, early_exit, (hipStream_t)stream, &ok) : 0;
+    return exdot_accumulate_on(ctx(-1), d_a, inca, d_b, incb, n, fpe, early_exit, (hipStream_t)stream);
 }
 
-int exblas_finish_dev(void *stream, int64_t *d_out)
-{
-    Ctx &c = ctx(-1);
-    std::lock_guard<std::mutex> lk(c.mu);
-    return (int)finalize_groups(c, (hipStream_t)stream, (long long *)d_out);
-}
+int exblas_finish_dev(void *stream, int64_t *d_out) { return finish_on(ctx(-1), (hipStream_t)stream, d_out); }
 
 int exblas_exsum_dev(const double *d_a, int64_t n, int64_t inca, int fpe, int early_exit, void *stream,
                      int64_t *d_out)
@@ -375,28 +465,19 @@ int exblas_finalize_dev(const int64_t *d_digit_sets, int nsets, uint32_t flags_o
 int exblas_exgemv_dev(char transa, int m, int n, double alpha, const double *d_a, int lda, const double *d_x,
                       int incx, double beta, double *d_y, int incy, int fpe, int early_exit, void *stream)
 {
-    if (fpe < 0) return (int)hipErrorInvalidValue;
-    Ctx &c = ctx(-1);
-    std::lock_guard<std::mutex> lk(c.mu);
-    return (int)exgemv_dispatch(c, transa, m, n, alpha, d_a, lda, d_x, incx, beta, d_y, incy, fpe, early_exit,
-                                round_mode(), (hipStream_t)stream);
+    return exgemv_on(ctx(-1), transa, m, n, alpha, d_a, lda, d_x, incx, beta, d_y, incy, fpe, early_exit,
+                     (hipStream_t)stream);
 }
 
 int exblas_extrsv_dev(char uplo, char transa, char diag, int n, const double *d_a, int lda, double *d_x, int incx,
                       int fpe, int early_exit, void *stream)
 {
-    if (fpe < 0) return (int)hipErrorInvalidValue;
-    if (fpe >= 9) return EXBLAS_UNSUPPORTED;
-    if (n > 0 && (lda < n || incx <= 0)) return (int)hipErrorInvalidValue;
-    Ctx &c = ctx(-1);
-    std::lock_guard<std::mutex> lk(c.mu);
-    return (int)extrsv_dispatch(c, uplo, transa, diag, n, d_a, lda, d_x, incx, fpe, early_exit, round_mode(),
-                                (hipStream_t)stream);
+    return extrsv_on(ctx(-1), uplo, transa, diag, n, d_a, lda, d_x, incx, fpe, early_exit, (hipStream_t)stream);
 }
 
 int exblas_extrsv_last_slow_rows(void)
 {
-    Ctx &c = ctx(-1);
+    Ctx &c = ctx(-1, g_last_layer[current_device()]);
     std::lock_guard<std::mutex> lk(c.mu);
     int v[4] = {0, 0, 0, 0};
     if (!c.ws || c.ws_bytes < sizeof(v)) return -1;
@@ -409,11 +490,32 @@ int exblas_exgemm_dev(char transa, char transb, int m, int n, int k, double alph
                       const double *d_b, int ldb, double beta, double *d_c, int ldc, int fpe, int early_exit,
                       void *stream)
 {
-    if (fpe < 0) return (int)hipErrorInvalidValue;
+    return exgemm_on(ctx(-1), transa, transb, m, n, k, alpha, d_a, lda, d_b, ldb, beta, d_c, ldc, fpe, early_exit,
+                     (hipStream_t)stream);
+}
+
+int exblas_reserve_workspace(size_t bytes)
+{
     Ctx &c = ctx(-1);
     std::lock_guard<std::mutex> lk(c.mu);
-    return (int)exgemm_dispatch(c, transa, transb, m, n, k, alpha, d_a, lda, d_b, ldb, beta, d_c, ldc, fpe,
-                                early_exit, round_mode(), (hipStream_t)stream);
+    hipError_t e = hipSuccess;
+    workspace(c, bytes, nullptr, &e);
+    return (int)e;
+}
+
+int exblas_release_retired_workspaces(void)
+{
+    ctx(-1);
+    hipError_t first = hipDeviceSynchronize();
+    for_each_layer(current_device(), [&](Ctx &c) {
+        std::lock_guard<std::mutex> lk(c.mu);
+        for (void *p : c.retired) {
+            hipError_t e = hipFree(p);
+            if (first == hipSuccess) first = e;
+        }
+        c.retired.clear();
+    });
+    return (int)first;
 }
 
 int exblas_gen_dev(int kind, uint64_t seed, int64_t first, int64_t count, int64_t n_total, double p0, double p1,
@@ -479,7 +581,7 @@ int exblas_exsum_record(int Ng, const double *ag, int inca, int offset, int fpe,
                         int64_t *out_words)
 {
     check_fpe(fpe);
-    Ctx &c = ctx(-1);
+    Ctx &c = ctx(-1, 1);
     std::lock_guard<std::mutex> api_lock(c.api_mu);
     const double *d_a = nullptr;
     {
@@ -493,9 +595,9 @@ int exblas_exsum_record(int Ng, const double *ag, int inca, int offset, int fpe,
             d_a = buf;
         }
     }
-    int rc = exblas_exsum_dev(d_a, Ng > 0 ? Ng : 0, inca > 0 ? inca : 1, fpe, early_exit, c.stream,
-                              (int64_t *)c.d_record);
-    if (rc) die("exblas_exsum_dev", (hipError_t)rc, __FILE__, __LINE__);
+    int rc = exsum_accumulate_on(c, d_a, Ng > 0 ? Ng : 0, inca > 0 ? inca : 1, fpe, early_exit, c.stream);
+    if (!rc) rc = finish_on(c, c.stream, (int64_t *)c.d_record);
+    if (rc) die("exblas_exsum", (hipError_t)rc, __FILE__, __LINE__);
     EXB_CHECK(hipMemcpyAsync(c.h_record, c.d_record, sizeof(long long) * OUT_WORDS, hipMemcpyDeviceToHost,
                              c.stream));
     EXB_CHECK(hipStreamSynchronize(c.stream));
@@ -507,7 +609,7 @@ int exblas_exdot_record(int Ng, const double *ag, int inca, int offseta, const d
                         int fpe, int early_exit, int64_t *out_words)
 {
     check_fpe(fpe);
-    Ctx &c = ctx(-1);
+    Ctx &c = ctx(-1, 1);
     std::lock_guard<std::mutex> api_lock(c.api_mu);
     const double *d_a = nullptr, *d_b = nullptr;
     {
@@ -523,9 +625,10 @@ int exblas_exdot_record(int Ng, const double *ag, int inca, int offseta, const d
             d_b = bb;
         }
     }
-    int rc = exblas_exdot_dev(d_a, inca > 0 ? inca : 1, d_b, incb > 0 ? incb : 1, Ng > 0 ? Ng : 0, fpe, early_exit,
-                              c.stream, (int64_t *)c.d_record);
-    if (rc) die("exblas_exdot_dev", (hipError_t)rc, __FILE__, __LINE__);
+    int rc = exdot_accumulate_on(c, d_a, inca > 0 ? inca : 1, d_b, incb > 0 ? incb : 1, Ng > 0 ? Ng : 0, fpe,
+                                 early_exit, c.stream);
+    if (!rc) rc = finish_on(c, c.stream, (int64_t *)c.d_record);
+    if (rc) die("exblas_exdot", (hipError_t)rc, __FILE__, __LINE__);
     EXB_CHECK(hipMemcpyAsync(c.h_record, c.d_record, sizeof(long long) * OUT_WORDS, hipMemcpyDeviceToHost,
                              c.stream));
     EXB_CHECK(hipStreamSynchronize(c.stream));
@@ -561,7 +664,7 @@ int exblas_exgemv(char transa, int m, int n, double alpha, const double *a, int 
 {
     check_fpe(fpe);
     if (m <= 0 || n <= 0) return 0;
-    Ctx &c = ctx(-1);
+    Ctx &c = ctx(-1, 1);
     std::lock_guard<std::mutex> api_lock(c.api_mu);
     const bool trans = (transa == 'T' || transa == 't');
     const int rows = trans ? n : m, inner = trans ? m : n;
@@ -578,8 +681,8 @@ int exblas_exgemv(char transa, int m, int n, double alpha, const double *a, int 
         EXB_CHECK(hipMemcpyAsync(d_x, x + offsetx, xspan * sizeof(double), hipMemcpyHostToDevice, c.stream));
         EXB_CHECK(hipMemcpyAsync(d_y, y + offsety, yspan * sizeof(double), hipMemcpyHostToDevice, c.stream));
     }
-    int rc = exblas_exgemv_dev(transa, m, n, alpha, d_a, lda, d_x, incx, beta, d_y, incy, fpe, early_exit, c.stream);
-    if (rc) die("exblas_exgemv_dev", (hipError_t)rc, __FILE__, __LINE__);
+    int rc = exgemv_on(c, transa, m, n, alpha, d_a, lda, d_x, incx, beta, d_y, incy, fpe, early_exit, c.stream);
+    if (rc) die("exblas_exgemv", (hipError_t)rc, __FILE__, __LINE__);
     EXB_CHECK(hipMemcpyAsync(y + offsety, d_y, yspan * sizeof(double), hipMemcpyDeviceToHost, c.stream));
     EXB_CHECK(hipStreamSynchronize(c.stream));
     return 0;
@@ -595,7 +698,7 @@ int exblas_extrsv(char uplo, char transa, char diag, int n, const double *a, int
         return -1;
     }
     if (n <= 0) return 0;
-    Ctx &c = ctx(-1);
+    Ctx &c = ctx(-1, 1);
     std::lock_guard<std::mutex> api_lock(c.api_mu);
     double *d_a, *d_x;
     const size_t abytes = ((size_t)lda * (size_t)(n - 1) + (size_t)n) * sizeof(double);  // n columns of lda
@@ -607,8 +710,8 @@ int exblas_extrsv(char uplo, char transa, char diag, int n, const double *a, int
         EXB_CHECK(hipMemcpyAsync(d_a, a + offseta, abytes, hipMemcpyHostToDevice, c.stream));
         EXB_CHECK(hipMemcpyAsync(d_x, x + offsetx, xspan * sizeof(double), hipMemcpyHostToDevice, c.stream));
     }
-    int rc = exblas_extrsv_dev(uplo, transa, diag, n, d_a, lda, d_x, incx, fpe, early_exit, c.stream);
-    if (rc) die("exblas_extrsv_dev", (hipError_t)rc, __FILE__, __LINE__);
+    int rc = extrsv_on(c, uplo, transa, diag, n, d_a, lda, d_x, incx, fpe, early_exit, c.stream);
+    if (rc) die("exblas_extrsv", (hipError_t)rc, __FILE__, __LINE__);
     EXB_CHECK(hipMemcpyAsync(x + offsetx, d_x, xspan * sizeof(double), hipMemcpyDeviceToHost, c.stream));
     EXB_CHECK(hipStreamSynchronize(c.stream));
     return 0;
@@ -619,7 +722,7 @@ int exblas_exgemm(char transa, char transb, int m, int n, int k, double alpha, c
 {
     check_fpe(fpe);
     if (m <= 0 || n <= 0) return 0;
-    Ctx &c = ctx(-1);
+    Ctx &c = ctx(-1, 1);
     std::lock_guard<std::mutex> api_lock(c.api_mu);
     const bool ta = (transa == 'T' || transa == 't'), tb = (transb == 'T' || transb == 't');
     // row-major storage (ExGEMM.Superacc.cl:254-255): A is m x k (k x m when transposed), etc.
@@ -636,9 +739,8 @@ int exblas_exgemm(char transa, char transb, int m, int n, int k, double alpha, c
         EXB_CHECK(hipMemcpyAsync(d_b, b, bbytes, hipMemcpyHostToDevice, c.stream));
         EXB_CHECK(hipMemcpyAsync(d_c, cm, cbytes, hipMemcpyHostToDevice, c.stream));
     }
-    int rc = exblas_exgemm_dev(transa, transb, m, n, k, alpha, d_a, lda, d_b, ldb, beta, d_c, ldc, fpe, early_exit,
-                               c.stream);
-    if (rc) die("exblas_exgemm_dev", (hipError_t)rc, __FILE__, __LINE__);
+    int rc = exgemm_on(c, transa, transb, m, n, k, alpha, d_a, lda, d_b, ldb, beta, d_c, ldc, fpe, early_exit, c.stream);
+    if (rc) die("exblas_exgemm", (hipError_t)rc, __FILE__, __LINE__);
     EXB_CHECK(hipMemcpyAsync(cm, d_c, cbytes, hipMemcpyDeviceToHost, c.stream));
     EXB_CHECK(hipStreamSynchronize(c.stream));
     return 0;

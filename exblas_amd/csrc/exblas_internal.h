@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <mutex>
+#include <vector>
 
 namespace exb {
 
@@ -34,16 +35,25 @@ struct Ctx {
     size_t stage_bytes[3] = {0, 0, 0};
     long long *d_record = nullptr;  // OUT_WORDS
     long long *h_record = nullptr;  // pinned
-    // blas2/blas3 workspaces
+    // blas2/blas3 workspaces.  Growth never frees the old block (a hipGraph captured earlier may still replay into
+    // it): it is parked in `retired` until exblas_release_retired_workspaces(); growth while the stream is being
+    // captured is refused (hipErrorStreamCaptureUnsupported) -- reserve first (exblas_reserve_workspace).
     void *ws = nullptr;
     size_t ws_bytes = 0;
+    std::vector<void *> retired;
+    int layer = 0;      // 0: the *_dev layer's context, >= 1: a private context of the host-pointer layer
     std::mutex mu;      // guards launches that touch the context workspace
     std::mutex api_mu;  // held by a host-pointer call for its whole duration (staging buffers, record, stream)
 };
 
-Ctx &ctx(int device);
+// layer 0: context of the device-pointer (*_dev) entry points; layers 1..: the host-pointer API's own contexts (own
+// accumulators, flags, workspace, stream; one per "virtual device" a host call spreads its data over), so that a
+// host call can never touch state an in-flight *_dev call uses
+constexpr int MAX_LAYERS = 9;
+Ctx &ctx(int device, int layer = 0);
 void *stage_buf(Ctx &c, int slot, size_t bytes);
-void *workspace(Ctx &c, size_t bytes);
+// nullptr + *err set when the block would have to grow while `st` is being captured into a graph
+void *workspace(Ctx &c, size_t bytes, hipStream_t st, hipError_t *err);
 [[noreturn]] void die(const char *what, hipError_t e, const char *file, int line);
 
 #define EXB_CHECK(expr)                                          \

@@ -411,9 +411,11 @@ hipError_t extrsv_dispatch(Ctx &c, char uplo, char transa, char diag, int n, con
     const int rev = (lower != trans) ? 0 : 1;  // A**T of a lower matrix is upper: backward substitution
     const long long rs = trans ? (long long)lda : 1ll, cs = trans ? 1ll : (long long)lda;
     // workspace: 16 ints (ticket, statistics) then the mailbox of n doubles
-    int *sync = (int *)workspace(c, 64 + (size_t)n * sizeof(double));
+    hipError_t e;
+    int *sync = (int *)workspace(c, 64 + (size_t)n * sizeof(double), st, &e);
+    if (!sync) return e;
     double *xq = (double *)((char *)sync + 64);
-    hipError_t e = hipMemsetAsync(sync, 0, 64, st);
+    e = hipMemsetAsync(sync, 0, 64, st);
     if (e != hipSuccess) return e;
     if ((e = hipMemsetAsync(xq, 0xff, (size_t)n * sizeof(double), st)) != hipSuccess) return e;
 #define TV_ARGS n, a, rs, cs, x, (long long)incx, rev, unit, round_mode, sync, xq, st

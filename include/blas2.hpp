@@ -4,7 +4,13 @@
 
 #include "config.h"
 
-/** Declared for source compatibility; the triangular solve is not part of this backend (returns -1). */
+/**
+ * Solves A*x = b or A**T*x = b for a triangular column-major A; x holds b on entry and the solution on return,
+ * every x_i = fl(Round(b_i - sum_j A(i,j)*x_j) / A(i,i)) with the sum exact.  uplo 'L'/'U', transa 'N'/'T',
+ * diag 'N'/'U'.  fpe == 0 superaccumulators only, fpe == 1 plain DTRSV, 2..8 expansions (early_exit buckets 4/6/8).
+ * Returns 0; fpe >= 9 (the reference's iterative-refinement kernels, which it does not ship, ExTRSV.cpp:91-120)
+ * prints a message, leaves x untouched and returns -1.
+ */
 int extrsv(const char uplo, const char transa, const char diag, const int n, double *a, const int lda,
            const int offseta, double *x, const int incx, const int offsetx, const int fpe,
            const bool early_exit = false);

@@ -18,11 +18,18 @@
  * hipError_t-compatible int instead of exiting (0 = success).
  *
  * Concurrency: the host-pointer layer may be called from any number of threads (calls on one device are
- * serialised; the reference's GPU library is not re-entrant at all, ExSUM.Launcher.cpp:16-36).  The *_dev layer
- * keeps ONE set of group accumulators and ONE workspace per device (two accumulator slots, see
+ * serialised; the reference's GPU library is not re-entrant at all, ExSUM.Launcher.cpp:16-36).  It owns a PRIVATE
+ * context per device -- its own group accumulators, flags, workspace, staging buffers and stream -- so a host call
+ * never touches state an in-flight *_dev call uses, and vice versa: the two layers may be mixed freely.
+ * The *_dev layer keeps ONE set of group accumulators and ONE workspace per device (two accumulator slots, see
  * exblas_set_accumulator_slot): its calls may come from any thread, but the work they enqueue must be ordered on
  * the device -- one stream, or streams chained by events -- exactly like kernels sharing a scratch buffer.
- * The first call of each kind allocates (hipMalloc): make it before capturing a stream into a hipGraph.
+ * Workspace and hipGraphs: exgemv / exgemm / extrsv use a context workspace whose size depends on the problem.  It
+ * only grows; a block it outgrows is parked (not freed) so that graphs captured earlier stay valid until
+ * exblas_release_retired_workspaces().  Growth needs hipMalloc, which is illegal while a stream is being captured:
+ * a call that would have to grow during capture fails with hipErrorStreamCaptureUnsupported (900) -- make the same
+ * call once before capturing, or exblas_reserve_workspace().  Every *_dev entry point is a pure sequence of
+ * stream-ordered launches: no host synchronisation, no device-to-host read, capturable.
  *
  * Rounding: EXBLAS_ROUND=exact (default; correctly rounded = the MPFR oracle of
  * tests/test.exsum.gpu.cpp:23-38) or EXBLAS_ROUND=reference (bug-compatible with
@@ -31,6 +38,7 @@
 #ifndef EXBLAS_HIP_H_
 #define EXBLAS_HIP_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -70,6 +78,11 @@ int exblas_set_tuning(int blocks_per_cu, int ngroups, int variant);
 void exblas_set_gemm_path(int mode);
 /* which implementation the last exgemm used: 0 = scalar kernel, 2..4 = MFMA path with that many slices */
 int exblas_last_gemm_slices(void);
+/* Makes the *_dev layer's workspace at least `bytes` large (see "Workspace and hipGraphs" above). */
+int exblas_reserve_workspace(size_t bytes);
+/* Frees the workspace blocks that later, larger calls replaced.  Synchronises the device; only call it when no graph
+ * captured before the growth will be replayed again. */
+int exblas_release_retired_workspaces(void);
 /* 0 = exact, 1 = reference; overrides EXBLAS_ROUND for the host-pointer API */
 void exblas_set_round_mode(int mode);
 int exblas_get_round_mode(void);
@@ -146,6 +159,71 @@ int exblas_stream_read_dev(const double *d_a, int64_t n, void *stream, double *d
 /* the same for the two-stream (ExDOT) access pattern: plain fp64 dot, blocks_per_cu <= 0 uses the ExDOT geometry */
 int exblas_stream_read2_dev(const double *d_a, const double *d_b, int64_t n, int blocks_per_cu, void *stream,
                             double *d_sink);
+
+/* ---- (2b) multi-GPU: one process per GPU ----------------------------------------------------- */
+/* The reference reduces across processes inside the library call: local reduction, MPI_Reduce(MPI_LONG, MPI_SUM) of
+ * the normalised limbs, Round on the root (src/cpu/blas/blas1/ExSUM.cpp:142-152, :266-273; scatter :33-63).  Here:
+ * local reduction on each GPU, ONE int64-sum all-reduce of the 576-byte digit set, the same carry-propagation +
+ * rounding kernel on every rank.  Integer addition is order-free, so the result is bit-identical for any number of
+ * ranks and any shard boundaries.  ExGEMV / ExGEMM shard the outputs (no reduction collective): x resp. B is
+ * replicated by one broadcast, y resp. C completed by an all-gather that overlaps the remaining compute.
+ *
+ * A communicator wraps a transport: RCCL (resolved at run time with dlopen("librccl.so.1"); collectives are
+ * enqueued on the caller's stream, nothing synchronises) or three host callbacks (what an MPI program passes to keep
+ * MPI_Allreduce / MPI_Bcast / MPI_Allgatherv as the transport, and what lets several ranks share one GPU in tests;
+ * this transport synchronises the stream around each callback).  All functions return 0, a hipError_t value, or
+ * EXBLAS_COMM_ERROR for a transport failure (message on stderr). */
+typedef struct exblas_comm exblas_comm_t;
+#define EXBLAS_UNIQUE_ID_BYTES 128
+#define EXBLAS_COMM_ERROR (-2)
+/* rank 0: make an id (ncclGetUniqueId) and hand the 128 bytes to every rank by any means (MPI_Bcast, a file, a store) */
+int exblas_comm_unique_id(void *id128);
+/* every rank, current device = its GPU: ncclCommInitRank */
+int exblas_comm_init_rccl(exblas_comm_t **comm, int nranks, int rank, const void *id128);
+/* wrap an ncclComm_t the application already has (not destroyed by exblas_comm_destroy) */
+int exblas_comm_adopt_rccl(exblas_comm_t **comm, void *nccl_comm, int nranks, int rank);
+/* host transport; the callbacks operate in place on host memory and return 0 on success:
+ *   allreduce: buf[0..count) := element-wise int64 sum over all ranks
+ *   bcast:     the root's `bytes` bytes of buf reach every rank
+ *   allgatherv: rank r owns bytes [off[r], off[r+1]) of buf (off has nranks+1 entries, off[0] == 0); afterwards every
+ *               rank holds all off[nranks] bytes */
+typedef int (*exblas_host_allreduce_i64_fn)(void *user, int64_t *buf, int64_t count);
+typedef int (*exblas_host_bcast_fn)(void *user, void *buf, int64_t bytes, int root);
+typedef int (*exblas_host_allgatherv_fn)(void *user, void *buf, const int64_t *off);
+int exblas_comm_init_host(exblas_comm_t **comm, int nranks, int rank, exblas_host_allreduce_i64_fn allreduce,
+                          exblas_host_bcast_fn bcast, exblas_host_allgatherv_fn allgatherv, void *user);
+int exblas_comm_destroy(exblas_comm_t *comm);
+int exblas_comm_rank(const exblas_comm_t *comm);
+int exblas_comm_size(const exblas_comm_t *comm);
+/* [first, last) of rank's contiguous shard of n items; boundaries are even, so fp64 shards stay 16-byte aligned */
+void exblas_shard_range(int64_t n, int rank, int nranks, int64_t *first, int64_t *last);
+/* ExSUM / ExDOT of the concatenation of every rank's local array(s): d_out (EXBLAS_OUT_WORDS int64, device) holds
+ * the SAME record on every rank.  = exblas_ex*_accumulate_dev + exblas_allreduce_finish_dev. */
+int exblas_exsum_allreduce_dev(exblas_comm_t *comm, const double *d_a_local, int64_t n_local, int64_t inca, int fpe,
+                               int early_exit, void *stream, int64_t *d_out);
+int exblas_exdot_allreduce_dev(exblas_comm_t *comm, const double *d_a_local, int64_t inca, const double *d_b_local,
+                               int64_t incb, int64_t n_local, int fpe, int early_exit, void *stream, int64_t *d_out);
+/* The second half alone: normalise the selected accumulator slot (exblas_finish_dev), all-reduce the digit set,
+ * carry-propagate + round.  A caller that pipelines reductions runs this on a second stream while the next streaming
+ * kernel fills the other slot (bench.py). */
+int exblas_allreduce_finish_dev(exblas_comm_t *comm, void *stream, int64_t *d_out);
+/* Row-sharded ExGEMV.  transa 'N': rank r owns rows [first, last) = exblas_shard_range(m, r, size) of A and y;
+ * d_a_local is that row block (column-major, leading dimension lda >= last - first).  transa 'T': rank r owns the
+ * OUTPUTS [first, last) of n, i.e. columns first..last-1 of A; d_a_local points at column `first`.  d_x is the full
+ * vector on every rank; x_root >= 0 broadcasts it from that rank first, x_root < 0 says it is already replicated.
+ * d_y is the full vector on every rank: on entry a rank's own part holds its input (beta != 0), on return every rank
+ * holds all of y (in-place all-gather). */
+int exblas_exgemv_sharded_dev(exblas_comm_t *comm, char transa, int m, int n, double alpha, const double *d_a_local,
+                              int lda, double *d_x, int incx, int x_root, double beta, double *d_y, int incy, int fpe,
+                              int early_exit, void *stream);
+/* Row-sharded ExGEMM (row-major): rank r owns rows [first, last) = exblas_shard_range(m, r, size) of op(A) and C;
+ * d_a_local points at the rank's first row of op(A) (for transa 'T': column `first` of the stored k x m matrix).
+ * d_b: all of op(B)'s storage on every rank, broadcast from b_root first when b_root >= 0.  d_c: the full m x ldc
+ * matrix on every rank; a rank's own rows hold its input (beta != 0); on return every rank holds all of C.  With the
+ * RCCL transport the all-gather of a finished row chunk overlaps the computation of the next one. */
+int exblas_exgemm_sharded_dev(exblas_comm_t *comm, char transa, char transb, int m, int n, int k, double alpha,
+                              const double *d_a_local, int lda, double *d_b, int ldb, int b_root, double beta,
+                              double *d_c, int ldc, int fpe, int early_exit, void *stream);
 
 /* ---- (1) host-pointer layer (reference semantics; copies H2D per call like gpu:ExSUM.cpp:126) -- */
 double exblas_exsum(int Ng, const double *ag, int inca, int offset, int fpe, int early_exit);

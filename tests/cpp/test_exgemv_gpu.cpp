@@ -13,6 +13,15 @@
 #include <cstring>
 #include <vector>
 
+#ifdef EXBLAS_VS_MPFR
+// the MPFR oracles of the reference's -DEXBLAS_VS_MPFR tests (tests/test.exgemv.gpu.cpp:35-103,
+// tests/test.exgemm.gpu.cpp:53-125), kept in oracle/libmpfr_oracle.so
+extern "C" void mpfr_exgemv(char trans, int m, int n, double alpha, const double *a, int lda, const double *x, int incx,
+                            double beta, const double *y, int incy, double *y_out);
+extern "C" void mpfr_exgemm_dots(int m, int n, int k, const double *a, int lda, const double *b, int ldb, double *d_out,
+                                 int ldd);
+#endif
+
 static bool same(const std::vector<double> &x, const std::vector<double> &y)
 {
     return std::memcmp(x.data(), y.data(), x.size() * sizeof(double)) == 0;
@@ -38,6 +47,14 @@ int main(int argc, char *argv[])
             exgemv(trans, m, n, 1.0, a.data(), m, 0, x.data(), 1, 0, 1.0, y.data(), 1, 0, fpe[v], ee[v]);
             if (!same(y, ref)) { pass = false; printf("exgemv %c fpe%d%s differs\n", trans, fpe[v], ee[v] ? "ee" : ""); }
         }
+#ifdef EXBLAS_VS_MPFR
+        {
+            std::vector<double> ym(rows);
+            mpfr_exgemv(trans, m, n, 1.0, a.data(), m, x.data(), 1, 1.0, y0.data(), 1, ym.data());
+            if (!same(ym, ref)) { pass = false; printf("exgemv %c differs from MPFR\n", trans); }
+            else printf("  exgemv %c == MPFR bit for bit (%d outputs)\n", trans, rows);
+        }
+#endif
         // plain evaluation and the library's DGEMV baseline (fpe == 1) agree to rounding
         std::vector<double> yd(y0.begin(), y0.begin() + rows);
         exgemv(trans, m, n, 1.0, a.data(), m, 0, x.data(), 1, 0, 1.0, yd.data(), 1, 0, 1);
@@ -66,6 +83,16 @@ int main(int argc, char *argv[])
             exgemm('N', 'N', g, g, g, 1.0, A.data(), g, B.data(), g, 1.0, C.data(), g, fpe[v], ee[v]);
             if (!same(C, ref)) { pass = false; printf("exgemm fpe%d%s differs\n", fpe[v], ee[v] ? "ee" : ""); }
         }
+#ifdef EXBLAS_VS_MPFR
+        {
+            // C0 + RN(A*B): the reference kernel's plain fp64 "+=" on the correctly rounded dot (ExGEMM.Superacc.cl:280)
+            std::vector<double> D((size_t)g * g);
+            mpfr_exgemm_dots(g, g, g, A.data(), g, B.data(), g, D.data(), g);
+            for (size_t t = 0; t < D.size(); ++t) D[t] = 1.0 * C0[t] + D[t];
+            if (!same(D, ref)) { pass = false; printf("exgemm differs from MPFR\n"); }
+            else printf("  exgemm 256^3 == MPFR bit for bit\n");
+        }
+#endif
         double nrm = 0, val = 0;
         for (int i = 0; i < g; ++i)
             for (int j = 0; j < g; ++j) {

@@ -10,6 +10,14 @@
 #include <cstdlib>
 #include <cstring>
 
+#ifdef EXBLAS_VS_MPFR
+// The reference's -DEXBLAS_VS_MPFR build sums with mpfr_add_d at 2098 bits (tests/test.exsum.gpu.cpp:20-38) and forms
+// exact 128-bit products at 4196 bits for the dot (tests/test.exdot.gpu.cpp:24-46).  Those two loops live in
+// oracle/libmpfr_oracle.so (oracle/mpfr_oracle.c), the checker this test links against.
+extern "C" double mpfr_exsum(long n, const double *a, long inca, long offset);
+extern "C" double mpfr_exdot(long n, const double *a, long inca, long offa, const double *b, long incb, long offb);
+#endif
+
 static bool same(double x, double y) { return std::memcmp(&x, &y, sizeof x) == 0 || (x != x && y != y); }
 
 int main(int argc, char *argv[])
@@ -64,6 +72,13 @@ int main(int argc, char *argv[])
         printf("  exdot with FPE%d%s and superacc = %.16g\n", dot_fpe[v], dot_ee[v] ? " early-exit" : "", d);
         if (!same(d, d0)) pass = false;
     }
+#ifdef EXBLAS_VS_MPFR
+    // every variant above equals s0 / d0 bit for bit; MPFR pins that value (the reference allows 1e-16 here,
+    // test.exsum.gpu.cpp:118-133 -- the criterion below is bit equality)
+    const double sm = mpfr_exsum(N, a, 1, 0), dm = mpfr_exdot(N, a, 1, 0, b, 1, 0);
+    printf("  exsum with MPFR = %.16g\n  exdot with MPFR = %.16g\n", sm, dm);
+    if (!same(s0, sm) || !same(d0, dm)) pass = false;
+#endif
     // reproducibility under repetition (RNGExample.cpp:300-325 compares repeated calls with !=)
     for (int r = 0; r < 5; ++r)
         if (!same(exsum(N, a, 1, 0, 8, true), s0)) pass = false;

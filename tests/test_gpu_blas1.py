@@ -93,7 +93,8 @@ def test_reference_api_semantics(ex, oracle):
     want = oracle.exsum(a, 0)
     assert ex.exsum(a.size, a, 1, 0, 0) == want
     assert ex.exsum(a.size, a, 1, 0, 8, True, True) == want
-    assert ex.exsum(a.size, a, 1, 0, 9) == 0.0            # unsupported variant -> 0.0 (gpu:ExSUM.cpp:83)
+    assert ex.exsum(a.size, a, 1, 0, 9, True) == 0.0      # early_exit with fpe > 8 -> 0.0 (gpu:ExSUM.cpp:72-83)
+    assert ex.exsum(a.size, a, 1, 0, 9) == want           # no early exit: ExSUM.FPE.cl with NBFPE = 9, same value (:80-81)
     assert ex.exsum(0, a, 1, 0, 4) == 0.0
     assert ex.exdot(0, a, 1, 0, a, 1, 0, 4) == 0.0        # ExDOT.cpp:70-71
     assert ex.exdot(a.size, a, 1, 0, a, 1, 0, 5) == oracle.exdot(a, a, 0)
@@ -164,6 +165,12 @@ def test_standalone_cpp_caller(ex):
     for argv in (["20"], ["20", "50", "0"], ["20", "1e32", "0", "i"], ["18", "2", "0", "n"]):
         r = subprocess.run([exe, *argv], capture_output=True, text=True, timeout=300)
         assert r.returncode == 0 and "TestPassed; ALL OK!" in r.stdout, (argv, r.stdout[-2000:], r.stderr[-2000:])
+    # the -DEXBLAS_VS_MPFR build of the same caller (tests/test.exsum.gpu.cpp:20-38,:118-133): every variant == MPFR
+    if os.path.exists(exe + "_mpfr"):
+        for argv in (["18"], ["18", "50", "0"], ["18", "1e32", "0", "i"], ["16", "50", "0", "n"]):
+            r = subprocess.run([exe + "_mpfr", *argv], capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0 and "TestPassed; ALL OK!" in r.stdout and "exsum with MPFR" in r.stdout, \
+                (argv, r.stdout[-2000:], r.stderr[-2000:])
 
 
 def test_concurrent_cpp_callers(ex):
@@ -294,3 +301,37 @@ def test_error_behaviour_matches_reference(ex):
                        cwd=__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
     assert r.returncode == 1 and "not reached" not in r.stdout
     assert "Size of floating-point expansion should be a positive number" in r.stderr
+
+
+def test_host_and_dev_layers_do_not_share_state(ex, oracle):
+    """A host-pointer call while a *_dev reduction is still in flight (no synchronisation in between): the host
+    layer has its own accumulators / workspace / stream, so neither result is disturbed."""
+    n = 1 << 22
+    x = ex.gen_dev("ill_cond", n, 5, 1e32)
+    h = oracle.gen("lognormal", 300001, 6, 0.0, 2.0)
+    want_dev = ex.read_record(ex.exsum_dev(x, 8, True)).exact
+    want_host = oracle.exsum(h, 0)
+    m, k = 96, 80
+    A = oracle.gen("fpuniform_signed", m * k, 7, 40, 20)
+    xv = oracle.gen("fpuniform_signed", k, 8, 40, 20)
+    want_y = oracle.exgemv("N", m, k, 1.0, A, m, xv, 0.0, np.zeros(m), 0)
+    for it in range(12):
+        rec = ex.exsum_dev(x, 8, True)                       # enqueued, not waited for
+        assert ex.exsum(h.size, h, 1, 0, 8, True) == want_host, it
+        y = np.zeros(m)
+        ex.exgemv("N", m, k, 1.0, A, m, 0, xv, 1, 0, 0.0, y, 1, 0, 8, True)
+        assert (y.view(np.int64) == want_y.view(np.int64)).all(), it
+        assert ex.read_record(rec).exact == want_dev, it
+
+
+def test_expansion_sizes_above_8(ex, oracle):
+    """Without early exit the reference builds its FPE kernel with NBFPE = fpe for any fpe (gpu:ExSUM.cpp:80-81,
+    ExDOT.cpp:93-94): the result is the same exact value.  With early exit and fpe > 8 it silently returns 0.0."""
+    a = oracle.gen("ill_cond", 20000, 9, 1e32)
+    b = oracle.gen("lognormal", 20000, 10, 0.0, 2.0)
+    s, d = oracle.exsum(a, 0), oracle.exdot(a, b, 0)
+    for fpe in (9, 10, 16):
+        assert ex.exsum(a.size, a, 1, 0, fpe, False) == s
+        assert ex.exdot(a.size, a, 1, 0, b, 1, 0, fpe, False) == d
+        assert ex.exsum(a.size, a, 1, 0, fpe, True) == 0.0
+        assert ex.exdot(a.size, a, 1, 0, b, 1, 0, fpe, True) == 0.0

@@ -155,13 +155,22 @@ def test_standalone_cpp_gemv_gemm_caller(ex):
         r = subprocess.run([os.path.join(root, "tests", "cpp", "test_exgemv_gpu"), *argv], capture_output=True,
                            text=True, timeout=600)
         assert r.returncode == 0 and "TestPassed; ALL OK!" in r.stdout, (argv, r.stdout[-2000:], r.stderr[-2000:])
+    # the -DEXBLAS_VS_MPFR build (tests/test.exgemv.gpu.cpp:35-103, test.exgemm.gpu.cpp:53-125): bit-equal to MPFR
+    exe = os.path.join(root, "tests", "cpp", "test_exgemv_gpu_mpfr")
+    if os.path.exists(exe):
+        r = subprocess.run([exe, "300", "260"], capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and "TestPassed; ALL OK!" in r.stdout and "exgemm 256^3 == MPFR" in r.stdout, \
+            (r.stdout[-2000:], r.stderr[-2000:])
 
 
-def test_full_size_configs_sampled(ex, oracle):
-    """BASELINE configs 4 and 5 at full size: ExGEMV m=n=32768 ('N', column-major, alpha=beta=1) and ExGEMM n=8192
-    (row-major), each checked on a sample of outputs against the oracle's exact dot of the corresponding row/column."""
+def test_full_size_configs_stripes(ex, oracle):
+    """BASELINE configs 4 and 5 at full size: ExGEMV m=n=32768 (column-major, alpha=beta=1) and ExGEMM n=8192
+    (row-major).  ExGEMV: EVERY output of one 256-row stripe ('N') and of one 256-column stripe ('T') against the
+    oracle.  ExGEMM: every output of one 256-row stripe (2M outputs) produced by the fast path equals the stripe
+    produced by the independent scalar kernel (TwoProd + expansions + per-thread superaccumulator), and a 256 x 48
+    block of that stripe equals the oracle."""
     import torch
-    rng = np.random.default_rng(11)
+    lib = ex.load_library()
     m = n = 32768
     a = ex.gen_dev("fpuniform", m * n, 11, 10.0, 0.0)
     x = ex.gen_dev("fpuniform", n, 12, 10.0, 0.0)
@@ -172,24 +181,36 @@ def test_full_size_configs_sampled(ex, oracle):
     ex.exgemv_dev("T", m, n, 1.0, a, m, x, 1.0, yt, 4, True)
     hx, hy0, hy, hyt = x.cpu().numpy(), y0.cpu().numpy(), y.cpu().numpy(), yt.cpu().numpy()
     A = a.view(n, m)                      # column-major: A[k, i] = A(i, k)
-    for i in rng.integers(0, m, 24):
-        row = A[:, int(i)].contiguous().cpu().numpy()
-        want = oracle.exdot(np.append(row, 1.0), np.append(hx, hy0[i]), 0)      # + beta*y_i as one more exact term
-        assert same_bits(hy[i], want), ("gemv N", i)
-        col = A[int(i), :].contiguous().cpu().numpy()
-        want_t = oracle.exdot(np.append(col, 1.0), np.append(hx, hy0[i]), 0)
-        assert same_bits(hyt[i], want_t), ("gemv T", i)
+    i0 = 20224                            # stripe of rows / columns i0 .. i0+255
+    rows = A[:, i0:i0 + 256].contiguous().cpu().numpy().reshape(-1)     # 256 x n block, column-major, lda = 256
+    want = oracle.exgemv("N", 256, n, 1.0, rows, 256, hx, 1.0, hy0[i0:i0 + 256].copy(), 0)
+    assert (_bits(hy[i0:i0 + 256]) == _bits(want)).all(), "gemv N stripe"
+    cols = A[i0:i0 + 256, :].contiguous().cpu().numpy().reshape(-1)     # m x 256 block, column-major, lda = m
+    want_t = oracle.exgemv("T", m, 256, 1.0, cols, m, hx, 1.0, hy0[i0:i0 + 256].copy(), 0)
+    assert (_bits(hyt[i0:i0 + 256]) == _bits(want_t)).all(), "gemv T stripe"
     del a, A
     N = 8192
     Am = ex.gen_dev("fpuniform", N * N, 14, 10.0, 0.0)
     Bm = ex.gen_dev("fpuniform", N * N, 15, 10.0, 0.0)
     C = torch.zeros(N * N, dtype=torch.float64, device="cuda")
     ex.exgemm_dev("N", "N", N, N, N, 1.0, Am, N, Bm, N, 0.0, C, N, 8, True)
-    assert ex.load_library().exblas_last_gemm_slices() == 3
-    A2, B2, C2 = Am.view(N, N), Bm.view(N, N), C.view(N, N)
-    for i, j in zip(rng.integers(0, N, 24), rng.integers(0, N, 24)):
-        want = oracle.exdot(A2[int(i)].cpu().numpy(), B2[:, int(j)].contiguous().cpu().numpy(), 0)
-        assert same_bits(float(C2[int(i), int(j)]), want), ("gemm", i, j)
+    assert lib.exblas_last_gemm_slices() >= 2              # the fast (MFMA) path ran
+    r0 = 5120
+    stripe = C.view(N, N)[r0:r0 + 256].clone()
+    Cs = torch.zeros(256 * N, dtype=torch.float64, device="cuda")
+    lib.exblas_set_gemm_path(1)                            # scalar kernel only
+    try:
+        ex.exgemm_dev("N", "N", 256, N, N, 1.0, Am[r0 * N:], N, Bm, N, 0.0, Cs, N, 8, True)
+        assert lib.exblas_last_gemm_slices() == 0
+    finally:
+        lib.exblas_set_gemm_path(0)
+    assert torch.equal(stripe.view(-1).view(torch.int64), Cs.view(torch.int64)), "gemm stripe: fast path != scalar kernel"
+    j0 = 4000
+    Ab = Am.view(N, N)[r0:r0 + 256].contiguous().cpu().numpy().reshape(-1)
+    Bb = Bm.view(N, N)[:, j0:j0 + 48].contiguous().cpu().numpy().reshape(-1)
+    wantc = oracle.exgemm("N", "N", 256, 48, N, 1.0, Ab, N, Bb, 48, 0.0, np.zeros(256 * 48), 48, 0)
+    got = stripe[:, j0:j0 + 48].contiguous().cpu().numpy().reshape(-1)
+    assert (_bits(got) == _bits(wantc)).all(), "gemm block vs oracle"
 
 
 def same_bits(x, y):
@@ -262,3 +283,31 @@ def test_exgemm_mfma_mixed_digit_counts(ex, oracle):
         ex.exgemm("N", "N", mm, nn, k, 1.0, a, k, b, nn, 1.0, c, nn, 8, True)
         assert lib.exblas_last_gemm_slices() == 3
         assert (_bits(c) == _bits(want)).all()
+
+
+def test_expansion_sizes_above_8_gemv_gemm(ex, oracle):
+    """fpe > 8: without early exit the same exact result (ExGEMV.cpp:103-104, ExGEMM.cpp:96-97); with early exit the
+    reference falls through to `return` and leaves y / C untouched -- for every data set, whichever ExGEMM path
+    (MFMA slices or scalar kernel) the data would have qualified for."""
+    m, n, k = 70, 52, 45
+    a = oracle.gen("fpuniform", m * n, 91, 10, 0)
+    x = oracle.gen("fpuniform", n, 92, 10, 0)
+    y0 = oracle.gen("fpuniform", m, 93, 10, 0)
+    want = oracle.exgemv("N", m, n, 1.0, a, m, x, 1.0, y0, 0)
+    A = oracle.gen("fpuniform", m * k, 94, 10, 0)
+    B = oracle.gen("fpuniform", k * n, 95, 10, 0)
+    C0 = oracle.gen("fpuniform", m * n, 96, 10, 0)
+    wantc = oracle.exgemm("N", "N", m, n, k, 1.0, A, k, B, n, 1.0, C0, n, 0)
+    for fpe in (9, 12):
+        y = y0.copy()
+        ex.exgemv("N", m, n, 1.0, a, m, 0, x, 1, 0, 1.0, y, 1, 0, fpe, False)
+        assert (_bits(y) == _bits(want)).all()
+        y = y0.copy()
+        ex.exgemv("N", m, n, 1.0, a, m, 0, x, 1, 0, 1.0, y, 1, 0, fpe, True)
+        assert (_bits(y) == _bits(y0)).all()
+        c = C0.copy()
+        ex.exgemm("N", "N", m, n, k, 1.0, A, k, B, n, 1.0, c, n, fpe, False)
+        assert (_bits(c) == _bits(wantc)).all()
+        c = C0.copy()
+        ex.exgemm("N", "N", m, n, k, 1.0, A, k, B, n, 1.0, c, n, fpe, True)
+        assert (_bits(c) == _bits(C0)).all()

@@ -1,7 +1,10 @@
-"""GPU test of the N > 1 path with several ranks SHARING the one GPU of the test box (gloo transport, HIP
-kernels): every rank reduces its shard with the HIP kernels, the digit sets are all-reduced, every rank runs the
-second finalize -- and the result must be bit-identical to the single-rank result, for 2 and 3 ranks, ExSUM and ExDOT.
-(The RCCL transport itself needs one GPU per rank; bench.py rehearses that call sequence with a 1-rank nccl group.)"""
+"""GPU tests of the native multi-GPU path (csrc/comm.hip) with several ranks SHARING the one GPU of the test box.
+
+Every rank calls the library's own entry points -- exblas_exsum_allreduce_dev, exblas_exdot_allreduce_dev,
+exblas_exgemv_sharded_dev, exblas_exgemm_sharded_dev -- with the HIP kernels doing the work; the collectives go through
+the library's host-callback transport over gloo (RCCL refuses two ranks on one device).  The results must be
+bit-identical to the single-rank results for 2 and 3 ranks, odd row splits included.  The RCCL transport itself is
+exercised with a one-rank communicator (test_rccl_transport_one_rank) and by bench.py --gpus N on a multi-GPU node."""
 import os
 import socket
 
@@ -19,7 +22,75 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n, q):
+M, N, K = 301, 222, 259     # gemm / gemv shapes: odd, so the even-cut shards are unequal
+NSUM = (1 << 22) + 10
+
+
+def _inputs(ex):
+    """the full (unsharded) operands, generated on the GPU by the counter-based generators"""
+    x = ex.gen_dev("ill_cond", NSUM, 1, 1e32)
+    y = ex.gen_dev("lognormal", NSUM, 2, 0.0, 2.0)
+    a_cm = ex.gen_dev("fpuniform_signed", M * N, 81, 40, 20)      # column-major M x N (gemv)
+    xv = ex.gen_dev("fpuniform_signed", max(M, N), 82, 40, 20)
+    yv = ex.gen_dev("fpuniform_signed", max(M, N), 83, 40, 20)
+    A = ex.gen_dev("fpuniform", M * K, 84, 10, 0)                  # row-major M x K
+    B = ex.gen_dev("fpuniform", K * N, 85, 10, 0)
+    C0 = ex.gen_dev("fpuniform", M * N, 86, 10, 0)
+    return x, y, a_cm, xv, yv, A, B, C0
+
+
+def _run_all(ex, torch, comm, rank, world):
+    """what one rank does; world == 1 with comm None computes the single-rank reference through the plain *_dev calls"""
+    x, y, a_cm, xv, yv, A, B, C0 = _inputs(ex)
+    out = {}
+    first, last = ex.shard_range(NSUM, rank, world)
+    for fpe, ee in ((8, True), (0, False)):
+        if comm is None:
+            rs, rd = ex.exsum_dev(x, fpe, ee), ex.exdot_dev(x, y, fpe, ee)
+        else:
+            rs = ex.exsum_allreduce(comm, x[first:last], fpe, ee)
+            rd = ex.exdot_allreduce(comm, x[first:last], y[first:last], fpe, ee)
+        for name, r in (("sum", rs), ("dot", rd)):
+            rec = ex.read_record(r)
+            out[f"{name}{fpe}"] = (rec.exact, rec.refmode, rec.canon.tolist())
+    r0, r1 = ex.row_block(M, rank, world)
+    c0, c1 = ex.row_block(N, rank, world)
+    for fpe, ee in ((8, True), (0, False), (4, False)):
+        # gemv 'N': rows r0..r1 of A (column-major: a strided slice -> made contiguous with lda = r1 - r0) and of y
+        yN = torch.zeros(M, dtype=torch.float64, device="cuda")
+        yN[r0:r1] = yv[:M][r0:r1]
+        xN = xv[:N].clone() if rank == 0 else torch.zeros(N, dtype=torch.float64, device="cuda")
+        if comm is None:
+            ex.exgemv_dev("N", M, N, 1.5, a_cm, M, xN, 1.0, yN, fpe, ee)
+        else:
+            a_loc = a_cm.view(N, M)[:, r0:r1].contiguous()
+            ex.exgemv_sharded(comm, "N", M, N, 1.5, a_loc, max(r1 - r0, 1), xN, 1.0, yN, fpe, ee)
+            assert (xN == xv[:N]).all()                      # x was broadcast from rank 0
+        out[f"gemvN{fpe}"] = yN.cpu().numpy().view(np.int64).tolist()
+        # gemv 'T': outputs c0..c1 = columns of A
+        yT = torch.zeros(N, dtype=torch.float64, device="cuda")
+        yT[c0:c1] = yv[:N][c0:c1]
+        xT = xv[:M].clone() if rank == 0 else torch.zeros(M, dtype=torch.float64, device="cuda")
+        if comm is None:
+            ex.exgemv_dev("T", M, N, 1.0, a_cm, M, xT, 1.0, yT, fpe, ee)
+        else:
+            ex.exgemv_sharded(comm, "T", M, N, 1.0, a_cm[c0 * M:], M, xT, 1.0, yT, fpe, ee)
+        out[f"gemvT{fpe}"] = yT.cpu().numpy().view(np.int64).tolist()
+    for fpe, ee in ((8, True), (0, False)):
+        Cm = torch.zeros(M * N, dtype=torch.float64, device="cuda")
+        Cm[r0 * N:r1 * N] = C0[r0 * N:r1 * N]
+        Bm = B.clone() if rank == 0 else torch.zeros(K * N, dtype=torch.float64, device="cuda")
+        if comm is None:
+            ex.exgemm_dev("N", "N", M, N, K, 1.0, A, K, Bm, N, 1.0, Cm, N, fpe, ee)
+        else:
+            ex.exgemm_sharded(comm, M, N, K, 1.0, A[r0 * K:], Bm, 1.0, Cm, fpe, ee)
+            assert (Bm == B).all()
+        out[f"gemm{fpe}"] = Cm.cpu().numpy().view(np.int64).tolist()
+    torch.cuda.synchronize()
+    return out
+
+
+def _worker(rank, world, port, q):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
@@ -31,19 +102,10 @@ def _worker(rank, world, port, n, q):
     try:
         import exblas_amd as ex
         torch.cuda.set_device(0)
-        first, last = ex.shard_range(n, rank, world)
-        x = ex.gen_dev("ill_cond", n, 1, 1e32, first=first, count=last - first, n_total=n)
-        y = ex.gen_dev("lognormal", n, 2, 0.0, 2.0, first=first, count=last - first, n_total=n)
-        out = []
-        for op in ("exsum", "exdot"):
-            rec = ex.exsum_dev(x, 8, True) if op == "exsum" else ex.exdot_dev(x, y, 8, True)
-            host = rec.cpu()                                  # gloo moves host memory
-            ex.allreduce_record(host)
-            rec.copy_(host)
-            ex.finalize_dev(rec[ex.OUT_DIGITS:ex.OUT_DIGITS + ex.SET_WORDS], out=rec)
-            r = ex.read_record(rec)
-            out.append((r.exact, r.canon.tolist()))
-        q.put((rank, out))
+        comm = ex.Comm.from_torch()          # gloo group -> the library's host-callback transport
+        assert comm.size == world and comm.rank == rank
+        q.put((rank, _run_all(ex, torch, comm, rank, world)))
+        comm.destroy()
     finally:
         dist.destroy_process_group()
 
@@ -53,21 +115,50 @@ def test_shared_gpu_ranks_bit_identical(world):
     import torch
     import torch.multiprocessing as mp
     import exblas_amd as ex
-    n = (1 << 22) + 10
-    x = ex.gen_dev("ill_cond", n, 1, 1e32)
-    y = ex.gen_dev("lognormal", n, 2, 0.0, 2.0)
-    one = [ex.read_record(ex.exsum_dev(x, 8, True)), ex.read_record(ex.exdot_dev(x, y, 8, True))]
-    torch.cuda.synchronize()
+    one = _run_all(ex, torch, None, 0, 1)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=240) for _ in range(world)]
+    res = [q.get(timeout=400) for _ in range(world)]
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
     for rank, out in res:
-        for k in range(2):
-            assert out[k][0] == one[k].exact and (np.array(out[k][1]) == one[k].canon).all(), (rank, k)
+        assert out.keys() == one.keys()
+        for key in one:
+            assert out[key] == one[key], (world, rank, key)
+
+
+def test_rccl_transport_one_rank():
+    """The RCCL transport end to end (ncclGetUniqueId, ncclCommInitRank, ncclAllReduce / ncclBroadcast /
+    ncclAllGather enqueued by libexblas.so on the caller's stream) with a communicator of one rank: same bits as the
+    plain calls, and the whole sequence is capturable into a hipGraph (no host synchronisation anywhere)."""
+    import torch
+    import exblas_amd as ex
+    os.environ["EXBLAS_COMM_FORCE"] = "1"     # issue the broadcasts / all-gathers although there is one rank
+    comm = ex.Comm.rccl(ex.Comm.unique_id(), 0, 1)
+    one = _run_all(ex, torch, None, 0, 1)
+    got = _run_all(ex, torch, comm, 0, 1)
+    for key in one:
+        assert got[key] == one[key], key
+    # graph capture of exsum + all-reduce + finalize
+    x = ex.gen_dev("ill_cond", 1 << 20, 3, 1e32)
+    rec = ex.new_record_buffer()
+    ex.exsum_allreduce(comm, x, 8, True, out=rec)       # allocations and RCCL's lazy set-up happen outside the capture
+    want = ex.read_record(rec)
+    s = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    rec2 = ex.new_record_buffer()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            ex.exsum_allreduce(comm, x, 8, True, out=rec2)
+    rec2.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    r2 = ex.read_record(rec2)
+    assert r2.exact == want.exact and (r2.canon == want.canon).all()
+    comm.destroy()
