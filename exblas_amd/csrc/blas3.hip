@@ -25,9 +25,13 @@ template <int N, bool EE>
 __global__ void __launch_bounds__(GM_THREADS) k_gemm(int ta, int tb, int m, int n, int k, double alpha,
                                                      const double *__restrict__ a, long long lda,
                                                      const double *__restrict__ b, long long ldb, double beta,
-                                                     double *__restrict__ c, long long ldc, int round_mode)
+                                                     double *__restrict__ c, long long ldc, int round_mode,
+                                                     const int *__restrict__ gate)
 {
     __shared__ long long acc[NL * GM_THREADS];          // 139,264 B: private column per thread
+    // Predicated launch: the int8 path (blas3_i8.hip) decides ON THE DEVICE whether the data qualifies for it; this
+    // kernel is enqueued behind it either way and does the work only when *gate says "scalar" (0).
+    if (gate && *gate != 0) return;
     __shared__ double As[GM_T][GM_KB + 1], Bs[GM_KB][GM_T + 1];
     const int tid = threadIdx.x, tx = tid & (GM_T - 1), ty = tid >> 4;
     const int i0 = blockIdx.y * GM_T, j0 = blockIdx.x * GM_T;
@@ -92,12 +96,12 @@ __global__ void __launch_bounds__(GM_THREADS) k_gemm(int ta, int tb, int m, int 
 template <int N, bool EE>
 static hipError_t gemm_variant(char transa, char transb, int m, int n, int k, double alpha, const double *a, int lda,
                                const double *b, int ldb, double beta, double *c, int ldc, int round_mode,
-                               hipStream_t st)
+                               hipStream_t st, const int *gate)
 {
     const int ta = (transa == 'T' || transa == 't'), tb = (transb == 'T' || transb == 't');
     dim3 grid((n + GM_T - 1) / GM_T, (m + GM_T - 1) / GM_T);
     hipLaunchKernelGGL((k_gemm<N, EE>), grid, dim3(GM_THREADS), 0, st, ta, tb, m, n, k, alpha, a, (long long)lda, b,
-                       (long long)ldb, beta, c, (long long)ldc, round_mode);
+                       (long long)ldb, beta, c, (long long)ldc, round_mode, gate);
     return hipGetLastError();
 }
 
@@ -108,22 +112,31 @@ hipError_t exgemm_dispatch(Ctx &c, char transa, char transb, int m, int n, int k
 {
     if (m <= 0 || n <= 0) return hipSuccess;
     c.last_gemm_slices = 0;
-    // MFMA-F64 fast path (blas3_mfma.hip): exact-rounding mode only; mode 0 = for the expansion variants when the
-    // data qualifies, 1 = never, 2 = for every variant.  Falls through to the scalar kernel otherwise.
-    if (round_mode == 0 && c.gemm_path != 1 && (fpe >= 3 || c.gemm_path == 2)) {
-        const bool variant_ok = early_exit ? (fpe <= 8) : true;  // early_exit with fpe > 8 is a no-op (ExGEMM.cpp:88-99)
-        if (variant_ok) {
+    c.gemm_info_dev = nullptr;
+    if (early_exit && fpe > 8) return hipSuccess;  // the reference's silent no-op (ExGEMM.cpp:88-99), on every path
+    const int *gate = nullptr;
+    if (c.gemm_path == 3) {
+        // fp64 slices on MFMA-F64 (blas3_mfma.hip): exact-rounding mode, host-decided
+        if (round_mode == 0) {
             hipError_t e = hipSuccess;
             if (exgemm_try_mfma(c, transa, transb, m, n, k, alpha, a, lda, b, ldb, beta, cmat, ldc, st, &e)) return e;
         }
+    } else if (c.gemm_path != 1) {
+        // int8 slices on the matrix cores (blas3_i8.hip) for every variant and both rounding modes: the result is the
+        // correctly rounded exact dot product whichever expansion size the caller names.  The scalar kernel below is
+        // enqueued behind it, predicated on the device-side decision.
+        bool launched = false;
+        hipError_t e = exgemm_i8(c, transa, transb, m, n, k, alpha, a, lda, b, ldb, beta, cmat, ldc, round_mode, st,
+                                 &launched, &gate);
+        if (e != hipSuccess) return e;
+        if (!launched) gate = nullptr;
     }
-#define GM_ARGS transa, transb, m, n, k, alpha, a, lda, b, ldb, beta, cmat, ldc, round_mode, st
+#define GM_ARGS transa, transb, m, n, k, alpha, a, lda, b, ldb, beta, cmat, ldc, round_mode, st, gate
     if (fpe < 3) return gemm_variant<0, false>(GM_ARGS);
     if (early_exit) {
         if (fpe <= 4) return gemm_variant<4, true>(GM_ARGS);
         if (fpe <= 6) return gemm_variant<6, true>(GM_ARGS);
-        if (fpe <= 8) return gemm_variant<8, true>(GM_ARGS);
-        return hipSuccess;
+        return gemm_variant<8, true>(GM_ARGS);
     }
     switch (fpe) {
     case 3: return gemm_variant<3, false>(GM_ARGS);

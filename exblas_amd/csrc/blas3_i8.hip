@@ -1,0 +1,582 @@
+// blas3_i8.hip -- ExGEMM on the int8 matrix cores of gfx950, exact by construction and fully stream-ordered.
+//
+// What it replaces: the reference kernel gemm (src/gpu/blas/blas3/ExGEMM.Superacc.cl:200-283, ExGEMM.FPE.cl:209-341)
+// keeps one 39-limb superaccumulator per thread and pushes every TwoProductFMA product through it.  Same result here,
+//     C_ij := beta*C_ij + Round( sum_l fl(alpha*A_il) * B_lj ),
+// but the O(mnk) work runs on v_mfma_i32_32x32x32_i8 (5 Pop/s dense on MI355X, 64x the fp64 matrix rate) and only the
+// O(mn) carry-propagate + round touches a long accumulator:
+//
+//   1. scan (gemm_scan.hip.h): per row i of A' = fl(alpha*A) a scale ea_i with |A'_il| < 2^ea_i and the lowest set bit;
+//      likewise per column j of B.  k_i8_decide turns the widest span into slice counts sa, sb ON THE DEVICE.
+//   2. slice ONCE (k_i8_slice_*): every entry is the integer X = x / 2^ua_i (ua_i = ea_i - 8*sa + 2), |X| < 2^(8sa-2),
+//      written as sa balanced base-256 digits d_t in [-128, 127], X = sum_t d_t 256^t -- integer shifts only, no
+//      rounding anywhere.  Digit t of all entries forms an int8 "plane".  Planes are stored tile-major
+//      ([64-row tile][64-byte k chunk][plane][4 KiB]) so that the GEMM kernel's global->LDS traffic is linear 4 KiB
+//      copies, with the 16-byte XOR swizzle the MFMA fragment reads need to be bank-conflict free already applied.
+//   3. contract (k_gemm_i8): a workgroup owns a 64 x 64 block of C, each of its 4 waves a 32 x 32 tile.  All digit
+//      pairs (p, q) with the same p + q share one int32 accumulator tile: |d_p d_q| <= 2^14, at most 8 pairs per
+//      group, k <= 8192 per pass  =>  |sum| <= 2^30: every MFMA partial sum is an exact integer.  The slice counts are
+//      read from device memory; digit pairs beyond (sa, sb) are skipped by wave-uniform scalar branches, so one
+//      instantiation serves every operand width up to 8 digits per pass with exactly sa*sb MFMAs per 32x32x32 block.
+//   4. the 15 group sums of a C entry are added, shifted by 8 bits per group, into a 192-bit two's-complement integer
+//      held in registers: the Kulisch accumulator of that entry, shrunk to the window the scales allow.  Operands
+//      wider than 8 digits (ill-conditioned data: up to 16) or k > 8192 take several passes; each pass adds its
+//      192-bit integer, shifted, into a 320-bit accumulator per entry in global memory and k_i8_finish rounds.
+//   5. round ONCE: correctly (round-to-nearest-even) or, for EXBLAS_ROUND=reference, by re-cutting the integer into
+//      the reference's 41 canonical limbs and running its Round() restated in superacc.hip.h -- so every (fpe,
+//      early_exit) variant and both rounding modes take this path; only Inf/NaN/subnormal inputs, exponents outside
+//      +-300 or spans beyond 16 digits fall back to the scalar kernel (blas3.hip), again decided on the device.
+//
+// Nothing synchronises with the host: kernels that turn out not to be needed (passes beyond the digit count, the
+// scalar fallback) are launched anyway and exit at their first instruction, so exblas_exgemm_dev can be captured into
+// a hipGraph.  Results are bit-identical to the scalar kernel, the oracle and MPFR (tests/test_gpu_blas23.py).
+#include "superacc.hip.h"
+#include "exblas_internal.h"
+#include "gemm_scan.hip.h"
+
+#include <type_traits>
+
+namespace exb {
+
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+typedef int v16i_t __attribute__((ext_vector_type(16)));
+
+constexpr int I8_T = 64;         // tile edge: rows (columns) per tile, and k bytes per chunk
+constexpr int I8_TILE = I8_T * I8_T;  // bytes of one plane of one tile
+constexpr int I8_SMAX = 8;       // digits per operand and pass (15 int32 accumulator groups per wave)
+constexpr int I8_SCAP = 16;      // digits per operand the path supports (2 x 2 passes)
+constexpr int I8_KPASS = 8192;   // k per pass: 8192 * 8 pairs * 2^14 = 2^30 < 2^31
+constexpr int I8_NWG = 5;        // 64-bit words of the per-entry accumulator in global memory (multi-pass)
+constexpr int I8_ERANGE = 300;   // |exponent| bound of the operands: keeps every rounded result a normal double
+
+enum { INFO_SA = 5, INFO_SB = 6, INFO_PATH = 7 };   // extends the scan's info block (INFO_WORDS == 8)
+enum { PATH_SCALAR = 0, PATH_I8 = 2 };
+
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for_i8(F &&f)
+{
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for_i8<B + 1, E>(f);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// decide: slice counts and path, on the device
+// ---------------------------------------------------------------------------------------------
+__global__ void k_i8_decide(int *info, int scap)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int path = PATH_I8;
+    if (info[INFO_FLAGS]) path = PATH_SCALAR;  // Inf / NaN / subnormal input
+    const bool nonzero = info[INFO_EMAX] >= info[INFO_EMIN];
+    if (nonzero && (info[INFO_EMIN] < -I8_ERANGE || info[INFO_EMAX] > I8_ERANGE)) path = PATH_SCALAR;
+    // |X| < 2^(8s-2) must hold with X a multiple of the lowest set bit: span + 2 bits in s digits
+    int sa = (info[INFO_NEED_A] + 2 + 7) / 8, sb = (info[INFO_NEED_B] + 2 + 7) / 8;
+    sa = sa < 1 ? 1 : sa;
+    sb = sb < 1 ? 1 : sb;
+    if (sa > scap || sb > scap) path = PATH_SCALAR;
+    info[INFO_SA] = sa;
+    info[INFO_SB] = sb;
+    info[INFO_PATH] = path;
+}
+
+// ---------------------------------------------------------------------------------------------
+// slicing
+// ---------------------------------------------------------------------------------------------
+// byte offset of (row r, k byte kb) inside a 4 KiB tile plane: rows of 64 bytes, the four 16-byte chunks of a row
+// permuted by (r >> 2) & 3 -- with that, the 16 lanes ds_read_b128 serves together (rows {0-3, 12-15, 20-27} + 32h of
+// one chunk column) fall into 16 different 16-byte bank groups
+__device__ __forceinline__ int tile_off(int r, int kb) { return r * I8_T + ((((kb >> 4) ^ (r >> 2)) & 3) << 4) + (kb & 15); }
+
+// 128-bit two's-complement integer in two words
+struct I128 {
+    unsigned long long lo;
+    long long hi;
+};
+
+// X = x / 2^u as an exact integer (the scan guarantees x is a multiple of 2^u and |X| < 2^(8s-2) <= 2^126)
+__device__ __forceinline__ I128 to_fixed(double x, int u)
+{
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(x);
+    const int be = (int)((bits >> 52) & 0x7ffu);
+    I128 r{0ull, 0ll};
+    if (be == 0) return r;  // zero (subnormals never reach this path)
+    const unsigned long long m = (bits & 0x000fffffffffffffull) | 0x0010000000000000ull;
+    const int sh = be - 1023 - 52 - u;  // >= -52: the bits shifted out below are zero by construction
+    if (sh >= 64) {
+        r.lo = 0;
+        r.hi = (long long)(m << (sh - 64));
+    } else if (sh > 0) {
+        r.lo = m << sh;
+        r.hi = (long long)(m >> (64 - sh));
+    } else {
+        r.lo = m >> (-sh);
+    }
+    if (bits >> 63) {  // negate
+        r.lo = ~r.lo + 1ull;
+        r.hi = ~r.hi + (r.lo == 0 ? 1 : 0);
+    }
+    return r;
+}
+
+// balanced base-256 digits, least significant first: d = (int8)(X & 255), X = (X - d) >> 8
+template <int S>
+__device__ __forceinline__ void digits(I128 X, int s, signed char (&d)[S])
+{
+#pragma unroll
+    for (int t = 0; t < S; ++t) {
+        signed char v = 0;
+        if (t < s) {
+            v = (signed char)(X.lo & 0xffull);
+            // X -= v (sign-extended), then arithmetic shift right by 8
+            const unsigned long long sub = (unsigned long long)(long long)v;
+            const unsigned long long lo = X.lo - sub;
+            const long long hi = X.hi - (long long)(v < 0 ? -1 : 0) - (X.lo < sub ? 1 : 0);
+            X.lo = (lo >> 8) | ((unsigned long long)hi << 56);
+            X.hi = hi >> 8;
+        }
+        d[t] = v;
+    }
+}
+
+// Source vectors CONTIGUOUS along k (A for 'N', B for 'T'): element (v, l) at src[v*ld + l].
+// One workgroup per (64-vector tile, 64-k chunk); thread = (vector tid/4, 16 consecutive k).
+template <int S>
+__global__ void __launch_bounds__(256) k_i8_slice_contig(const double *__restrict__ src, long long ld, int nvec, int len,
+                                                         double scale, const int *__restrict__ E,
+                                                         const int *__restrict__ info, int which,
+                                                         signed char *__restrict__ planes)
+{
+    if (info[INFO_PATH] != PATH_I8) return;
+    const int s = info[which ? INFO_SB : INFO_SA];
+    const int kc = blockIdx.x, vt = blockIdx.y, KC = gridDim.x;
+    const int r = threadIdx.x >> 2, seg = threadIdx.x & 3;
+    const int v = vt * I8_T + r, l0 = kc * I8_T + seg * 16;
+    const int u = (v < nvec ? E[v] : 0) - 8 * s + 2;
+    signed char dg[16][S];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int l = l0 + e;
+        const double x = (v < nvec && l < len) ? scale * src[(long long)v * ld + l] : 0.0;
+        digits<S>(to_fixed(x, u), s, dg[e]);
+    }
+    signed char *tile = planes + ((size_t)vt * KC + kc) * (size_t)s * I8_TILE;
+#pragma unroll
+    for (int t = 0; t < S; ++t) {
+        if (t < s) {
+            union { v4i_t v; signed char b[16]; } pk;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) pk.b[e] = dg[e][t];
+            *(v4i_t *)(tile + (size_t)t * I8_TILE + tile_off(r, seg * 16)) = pk.v;
+        }
+    }
+}
+
+// Source vectors STRIDED along k (A for 'T', B for 'N'): element (v, l) at src[l*ld + v]; adjacent vectors are
+// contiguous, so a wave reads 64 vectors x one l per load.  thread = (vector tid%64, 16 consecutive k).
+template <int S>
+__global__ void __launch_bounds__(256) k_i8_slice_strided(const double *__restrict__ src, long long ld, int nvec, int len,
+                                                          double scale, const int *__restrict__ E,
+                                                          const int *__restrict__ info, int which,
+                                                          signed char *__restrict__ planes)
+{
+    if (info[INFO_PATH] != PATH_I8) return;
+    const int s = info[which ? INFO_SB : INFO_SA];
+    const int kc = blockIdx.x, vt = blockIdx.y, KC = gridDim.x;
+    const int r = threadIdx.x & 63, seg = threadIdx.x >> 6;
+    const int v = vt * I8_T + r, l0 = kc * I8_T + seg * 16;
+    const int u = (v < nvec ? E[v] : 0) - 8 * s + 2;
+    signed char dg[16][S];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int l = l0 + e;
+        const double x = (v < nvec && l < len) ? scale * src[(long long)l * ld + v] : 0.0;
+        digits<S>(to_fixed(x, u), s, dg[e]);
+    }
+    signed char *tile = planes + ((size_t)vt * KC + kc) * (size_t)s * I8_TILE;
+#pragma unroll
+    for (int t = 0; t < S; ++t) {
+        if (t < s) {
+            union { v4i_t v; signed char b[16]; } pk;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) pk.b[e] = dg[e][t];
+            *(v4i_t *)(tile + (size_t)t * I8_TILE + tile_off(r, seg * 16)) = pk.v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// wide two's-complement integers
+// ---------------------------------------------------------------------------------------------
+// acc += sign_extend(T) << SH   (SH compile-time)
+template <int NW, int SH>
+__device__ __forceinline__ void wide_add_c(unsigned long long (&acc)[NW], long long T)
+{
+    constexpr int w = SH >> 6, b = SH & 63;
+    const unsigned long long ext = (unsigned long long)(T >> 63);
+    const unsigned long long lo = (unsigned long long)T << b;
+    const unsigned long long hi = b ? (unsigned long long)(T >> (64 - b)) : ext;
+    unsigned long long c = 0, cn;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        const unsigned long long v = (i < w) ? 0ull : (i == w ? lo : (i == w + 1 ? hi : ext));
+        acc[i] = __builtin_addcll(acc[i], v, c, &cn);
+        c = cn;
+    }
+}
+
+// dst (ND words) += sign_extend(src (3 words)) << sh, sh >= 0 a runtime multiple of 8
+template <int ND>
+__device__ __forceinline__ void wide_add_v(unsigned long long (&dst)[ND], const unsigned long long (&src)[3], int sh)
+{
+    const int w = sh >> 6, b = sh & 63;
+    const unsigned long long ext = (unsigned long long)((long long)src[2] >> 63);
+    unsigned long long c = 0, cn;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+        // word i of (src << sh): bits from src word i-w (<< b) and src word i-w-1 (>> 64-b)
+        auto word = [&](int j) -> unsigned long long { return j < 0 ? 0ull : (j < 3 ? src[j] : ext); };
+        const int j = i - w;
+        unsigned long long v = word(j) << b;
+        if (b) v |= word(j - 1) >> (64 - b);
+        if (j < 0) v = 0;
+        dst[i] = __builtin_addcll(dst[i], v, c, &cn);
+        c = cn;
+    }
+}
+
+// round the NW-word two's-complement integer times 2^unit_exp to nearest-even; the caller guarantees a normal result
+template <int NW>
+__device__ inline double wide_round_n(const unsigned long long (&in)[NW], int unit_exp)
+{
+    unsigned long long m[NW];
+    const bool neg = (long long)in[NW - 1] < 0;
+    {
+        unsigned long long c = neg ? 1 : 0, cn;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            m[i] = neg ? __builtin_addcll(~in[i], 0ull, c, &cn) : in[i];
+            c = neg ? cn : 0;
+        }
+    }
+    int top = NW - 1;
+    while (top > 0 && m[top] == 0) --top;
+    if (m[top] == 0) return 0.0;
+    const int lz = __builtin_clzll(m[top]);
+    const int msb = 64 * top + 63 - lz;
+    double r;
+    if (msb <= 52) {
+        r = ldexp((double)m[0], unit_exp);
+    } else {
+        const unsigned long long below = top > 0 ? m[top - 1] : 0ull;
+        const unsigned long long w = lz ? ((m[top] << lz) | (below >> (64 - lz))) : m[top];
+        bool sticky = (w & 0x3ffull) != 0 || (lz ? (below << lz) != 0 : below != 0);
+        for (int i = top - 2; i >= 0; --i) sticky |= m[i] != 0;
+        unsigned long long mant = w >> 11;
+        if (((w >> 10) & 1ull) && (sticky || (mant & 1ull))) mant += 1;  // may reach 2^53: still exact in fp64
+        r = ldexp((double)mant, msb - 52 + unit_exp);
+    }
+    return neg ? -r : r;
+}
+
+// The reference's rounding on the same integer: cut value = W * 2^unit_exp into the canonical 41 x 52-bit limbs
+// (limb j = bits [52(j-21), 52(j-20)) of the value, the top limb signed; superaccumulator.cpp:14-22) and run its
+// Round() (round_reference, superacc.hip.h).  Bits of the value below 2^-1092 cannot occur on this path (|e| <= 300).
+template <int NW>
+__device__ inline double wide_round_reference(const unsigned long long (&in)[NW], int unit_exp)
+{
+    long long canon[CANON];
+    auto bit_field = [&](long long o, bool top) -> long long {
+        // 64-bit window of W starting at bit o (o may be negative or beyond the integer): sign-extended two's complement
+        const unsigned long long ext = (unsigned long long)((long long)in[NW - 1] >> 63);
+        auto word = [&](long long i) -> unsigned long long { return i < 0 ? 0ull : (i < NW ? in[i] : ext); };
+        unsigned long long win;
+        if (o <= -64) {
+            win = 0;
+        } else if (o < 0) {
+            win = word(0) << (-o);  // low bits of the window lie below the integer: zeros
+        } else {
+            const long long q = o >> 6;
+            const int r = (int)(o & 63);
+            win = r ? ((word(q) >> r) | (word(q + 1) << (64 - r))) : word(q);
+        }
+        return top ? (long long)win : (long long)(win & ((1ull << CANON_DIGITS) - 1));
+    };
+    for (int j = 0; j < CANON; ++j)
+        canon[j] = bit_field((long long)CANON_DIGITS * (j - CANON_FWORDS) - unit_exp, j == CANON - 1);
+    return round_reference(canon);
+}
+
+// ---------------------------------------------------------------------------------------------
+// the contraction
+// ---------------------------------------------------------------------------------------------
+// XCD-aware tile order (speed only).  Workgroups b and b + 8 share an XCD and its L2: an XCD works through
+// "supertiles" of 8 x 4 tiles (its 32 CUs at a time), which need 8 A tile streams + 4 B tile streams from beyond L2
+// instead of 1 + 32; all XCDs sweep the column supertiles in the same order, so a B stream fetched from HBM by one
+// XCD is an Infinity-Cache hit for the other seven.
+__device__ __forceinline__ void tile_of_block(int bid, int nbid, int gy, int gx, int *ty, int *tx)
+{
+    const int q = nbid / 8, rem = nbid % 8, xcd = bid % 8;
+    const int lin = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + bid / 8;  // bijective
+    constexpr int SR = 8, SC = 4;
+    const int per_band = SR * gx;           // tiles in a band of SR tile rows
+    const int band = lin / per_band, inb = lin % per_band;
+    const int rows_here = min(SR, gy - band * SR);
+    const int sc = inb / (rows_here * SC), ins = inb % (rows_here * SC);
+    const int cols_here = min(SC, gx - sc * SC);
+    // inside a (rows_here x cols_here) supertile: column fastest (only the last supertile of a band can be ragged, and
+    // ins then already runs over rows_here * cols_here tiles)
+    const int ry = ins / cols_here, cx = ins % cols_here;
+    *ty = band * SR + ry;
+    *tx = sc * SC + cx;
+}
+
+// One pass: C block (64 x 64 per workgroup) += digits [ta0, ta0+8) of A  x  digits [tb0, tb0+8) of B over k chunks
+// [kc0, kc1).  single != 0: this pass is the whole product -> round and write C; else add into the global accumulator.
+__global__ void __launch_bounds__(256, 1) k_gemm_i8(int m, int n, int KC, int kc0, int kc1, int ta0, int tb0,
+                                                    const signed char *__restrict__ PA,
+                                                    const signed char *__restrict__ PB, const int *__restrict__ info,
+                                                    const int *__restrict__ EA, const int *__restrict__ EB,
+                                                    double beta, double *__restrict__ c, long long ldc, int round_mode,
+                                                    int allow_single, unsigned long long *__restrict__ W)
+{
+    constexpr int G = 2 * I8_SMAX - 1;
+    __shared__ v4i_t lds[2][2 * I8_SMAX * (I8_TILE / 16)];  // [buffer][A planes | B planes][256 x 16 B]: 128 KiB
+    if (info[INFO_PATH] != PATH_I8) return;
+    const int sa_all = info[INFO_SA], sb_all = info[INFO_SB];
+    if (ta0 >= sa_all || tb0 >= sb_all) return;
+    const int sa = min(I8_SMAX, sa_all - ta0), sb = min(I8_SMAX, sb_all - tb0);
+    const bool single = allow_single && sa_all <= I8_SMAX && sb_all <= I8_SMAX;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int gy = (m + I8_T - 1) / I8_T, gx = (n + I8_T - 1) / I8_T;
+    int ty, tx;
+    tile_of_block(blockIdx.x, gridDim.x, gy, gx, &ty, &tx);
+    const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
+
+    // tile streams: [tile][kc][plane][4 KiB]; this thread moves bytes [16 tid, 16 tid + 16) of every plane
+    const signed char *pa = PA + ((size_t)ty * KC * sa_all + ta0) * I8_TILE + (size_t)tid * 16;
+    const signed char *pb = PB + ((size_t)tx * KC * sb_all + tb0) * I8_TILE + (size_t)tid * 16;
+    const size_t stride_a = (size_t)sa_all * I8_TILE, stride_b = (size_t)sb_all * I8_TILE;
+
+    v4i_t ra[I8_SMAX], rb[I8_SMAX];
+    auto gload = [&](int kc) {
+#pragma unroll
+        for (int p = 0; p < I8_SMAX; ++p)
+            if (p < sa) ra[p] = *(const v4i_t *)(pa + kc * stride_a + (size_t)p * I8_TILE);
+#pragma unroll
+        for (int q = 0; q < I8_SMAX; ++q)
+            if (q < sb) rb[q] = *(const v4i_t *)(pb + kc * stride_b + (size_t)q * I8_TILE);
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < I8_SMAX; ++p)
+            if (p < sa) lds[buf][p * 256 + tid] = ra[p];
+#pragma unroll
+        for (int q = 0; q < I8_SMAX; ++q)
+            if (q < sb) lds[buf][(I8_SMAX + q) * 256 + tid] = rb[q];
+    };
+
+    v16i_t acc[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[g][r] = 0;
+
+    // fragment addresses (in 16-byte units inside a plane): lane -> row (lane & 31), chunk (2 ks + lane / 32), swizzled
+    const int arow = wr + (lane & 31), brow = wc + (lane & 31), half = lane >> 5;
+    int aoff[2], boff[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        aoff[ks] = tile_off(arow, (2 * ks + half) * 16) >> 4;
+        boff[ks] = tile_off(brow, (2 * ks + half) * 16) >> 4;
+    }
+
+    gload(kc0);
+    lstore(0);
+    __syncthreads();
+    for (int kc = kc0; kc < kc1; ++kc) {
+        const int buf = (kc - kc0) & 1;
+        if (kc + 1 < kc1) gload(kc + 1);  // in flight while this chunk is contracted
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            v4i_t fa[I8_SMAX], fb[I8_SMAX];
+#pragma unroll
+            for (int p = 0; p < I8_SMAX; ++p)
+                if (p < sa) fa[p] = lds[buf][p * 256 + aoff[ks]];
+#pragma unroll
+            for (int q = 0; q < I8_SMAX; ++q)
+                if (q < sb) fb[q] = lds[buf][(I8_SMAX + q) * 256 + boff[ks]];
+#pragma unroll
+            for (int p = 0; p < I8_SMAX; ++p) {
+                if (p < sa) {
+#pragma unroll
+                    for (int q = 0; q < I8_SMAX; ++q)
+                        if (q < sb) acc[p + q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[p], fb[q], acc[p + q], 0, 0, 0);
+                }
+            }
+        }
+        if (kc + 1 < kc1) lstore(buf ^ 1);  // that buffer was last read one iteration ago, before the barrier below
+        __syncthreads();
+    }
+
+    // ---- epilogue: 15 group sums -> one 192-bit integer per entry; C layout of the 32x32 MFMA:
+    // col = lane & 31, row = 8 * (r / 4) + 4 * (lane / 32) + (r % 4)
+    const int gj = tx * I8_T + wc + (lane & 31);
+    const int ebj = gj < n ? EB[gj] : 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        unsigned long long w3[3] = {0ull, 0ull, 0ull};
+        static_for_i8<0, G>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            wide_add_c<3, 8 * g>(w3, (long long)acc[g][r]);
+        });
+        const int gi = ty * I8_T + wr + 8 * (r >> 2) + 4 * half + (r & 3);
+        if (gi < m && gj < n) {
+            // unit of this pass's integer: 2^(ua + ub) * 256^(ta0 + tb0), ua = ea - 8 sa + 2
+            const int u0 = EA[gi] - 8 * sa_all + 2 + ebj - 8 * sb_all + 2;
+            if (single) {
+                const double s = round_mode ? wide_round_reference<3>(w3, u0 + 8 * (ta0 + tb0))
+                                            : wide_round_n<3>(w3, u0 + 8 * (ta0 + tb0));
+                double *cij = c + (long long)gi * ldc + gj;
+                *cij = (beta == 0.0) ? s : beta * (*cij) + s;
+            } else {
+                unsigned long long *wg = W + ((size_t)gi * n + gj) * I8_NWG;
+                unsigned long long acc5[I8_NWG];
+#pragma unroll
+                for (int i = 0; i < I8_NWG; ++i) acc5[i] = wg[i];
+                wide_add_v<I8_NWG>(acc5, w3, 8 * (ta0 + tb0));
+#pragma unroll
+                for (int i = 0; i < I8_NWG; ++i) wg[i] = acc5[i];
+            }
+        }
+    }
+}
+
+// multi-pass epilogue: round the 320-bit accumulators
+__global__ void __launch_bounds__(256) k_i8_finish(int m, int n, const int *__restrict__ info,
+                                                   const int *__restrict__ EA, const int *__restrict__ EB, double beta,
+                                                   double *__restrict__ c, long long ldc, int round_mode, int force_multi,
+                                                   const unsigned long long *__restrict__ W)
+{
+    if (info[INFO_PATH] != PATH_I8) return;
+    const int sa = info[INFO_SA], sb = info[INFO_SB];
+    if (!force_multi && sa <= I8_SMAX && sb <= I8_SMAX) return;  // the single pass wrote C itself
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)m * n) return;
+    const int gi = (int)(idx / n), gj = (int)(idx % n);
+    unsigned long long w[I8_NWG];
+#pragma unroll
+    for (int i = 0; i < I8_NWG; ++i) w[i] = W[(size_t)idx * I8_NWG + i];
+    const int u0 = EA[gi] - 8 * sa + 2 + EB[gj] - 8 * sb + 2;
+    const double s = round_mode ? wide_round_reference<I8_NWG>(w, u0) : wide_round_n<I8_NWG>(w, u0);
+    double *cij = c + (long long)gi * ldc + gj;
+    *cij = (beta == 0.0) ? s : beta * (*cij) + s;
+}
+
+__global__ void __launch_bounds__(256) k_i8_zero_w(long long words, const int *__restrict__ info, int force_multi,
+                                                   unsigned long long *__restrict__ W)
+{
+    if (info[INFO_PATH] != PATH_I8) return;
+    if (!force_multi && info[INFO_SA] <= I8_SMAX && info[INFO_SB] <= I8_SMAX) return;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < words; i += (long long)gridDim.x * 256) W[i] = 0ull;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side: a pure sequence of launches
+// ---------------------------------------------------------------------------------------------
+// Returns hipSuccess with *launched = true when the int8 path was enqueued (it may still decide, on the device, to
+// leave the work to the scalar kernel: the caller enqueues that one predicated on info[INFO_PATH]).
+// *launched = false: not attempted (k == 0, workspace unavailable) -> the caller runs the scalar kernel unconditionally.
+hipError_t exgemm_i8(Ctx &c, char transa, char transb, int m, int n, int k, double alpha, const double *a, int lda,
+                     const double *b, int ldb, double beta, double *cmat, int ldc, int round_mode, hipStream_t st,
+                     bool *launched, const int **gate)
+{
+    *launched = false;
+    *gate = nullptr;
+    if (k <= 0 || m <= 0 || n <= 0) return hipSuccess;
+    const int ta = (transa == 'T' || transa == 't'), tb = (transb == 'T' || transb == 't');
+    const int gy = (m + I8_T - 1) / I8_T, gx = (n + I8_T - 1) / I8_T, KC = (k + I8_T - 1) / I8_T;
+    int scap = c.gemm_max_slices > 0 ? c.gemm_max_slices : I8_SCAP;
+    if (scap > I8_SCAP) scap = I8_SCAP;
+    const int kpasses = (k + I8_KPASS - 1) / I8_KPASS;
+    const bool maybe_multi = scap > I8_SMAX || kpasses > 1;
+    // workspace: info | EA EB LA LB | planes of A | planes of B | W
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        const size_t o = off;
+        off += (bytes + 255) & ~(size_t)255;
+        return o;
+    };
+    const size_t o_info = take(sizeof(int) * INFO_WORDS);
+    const size_t o_e = take(sizeof(int) * 2 * ((size_t)m + n));
+    const size_t o_pa = take((size_t)gy * KC * scap * I8_TILE);
+    const size_t o_pb = take((size_t)gx * KC * scap * I8_TILE);
+    const size_t o_w = take(maybe_multi ? (size_t)m * n * I8_NWG * sizeof(unsigned long long) : 0);
+    hipError_t e = hipSuccess;
+    char *base = (char *)workspace(c, off, st, &e);
+    if (!base) {
+        if (e == hipErrorStreamCaptureUnsupported) return e;  // the caller must reserve before capturing
+        return hipSuccess;                                    // out of memory: scalar kernel
+    }
+    int *info = (int *)(base + o_info);
+    int *EA = (int *)(base + o_e), *EB = EA + m, *LA = EB + n, *LB = LA + m;
+    signed char *PA = (signed char *)(base + o_pa), *PB = (signed char *)(base + o_pb);
+    unsigned long long *W = (unsigned long long *)(base + o_w);
+
+    // ---- scan (shared with the fp64-slice path) ----
+    hipLaunchKernelGGL(k_scan_init, dim3((m + n + 255) / 256), dim3(256), 0, st, m + n, EA, LA, info);
+    const int ysplit = k >= 2048 ? 32 : (k >= 256 ? 8 : 1);
+    if (!ta)
+        hipLaunchKernelGGL(k_scan_contig, dim3(m), dim3(256), 0, st, a, (long long)lda, m, k, alpha, EA, LA, info);
+    else
+        hipLaunchKernelGGL(k_scan_strided, dim3((m + 255) / 256, ysplit), dim3(256), 0, st, a, (long long)lda, m, k, alpha,
+                           EA, LA, info);
+    if (!tb)
+        hipLaunchKernelGGL(k_scan_strided, dim3((n + 255) / 256, ysplit), dim3(256), 0, st, b, (long long)ldb, n, k, 1.0,
+                           EB, LB, info);
+    else
+        hipLaunchKernelGGL(k_scan_contig, dim3(n), dim3(256), 0, st, b, (long long)ldb, n, k, 1.0, EB, LB, info);
+    hipLaunchKernelGGL(k_scan_finish, dim3((m + 255) / 256), dim3(256), 0, st, m, EA, LA, info, INFO_NEED_A);
+    hipLaunchKernelGGL(k_scan_finish, dim3((n + 255) / 256), dim3(256), 0, st, n, EB, LB, info, INFO_NEED_B);
+    hipLaunchKernelGGL(k_i8_decide, dim3(1), dim3(64), 0, st, info, scap);
+
+    // ---- slice once ----
+    if (!ta)
+        hipLaunchKernelGGL((k_i8_slice_contig<I8_SCAP>), dim3(KC, gy), dim3(256), 0, st, a, (long long)lda, m, k, alpha,
+                           EA, info, 0, PA);
+    else
+        hipLaunchKernelGGL((k_i8_slice_strided<I8_SCAP>), dim3(KC, gy), dim3(256), 0, st, a, (long long)lda, m, k, alpha,
+                           EA, info, 0, PA);
+    if (!tb)
+        hipLaunchKernelGGL((k_i8_slice_strided<I8_SCAP>), dim3(KC, gx), dim3(256), 0, st, b, (long long)ldb, n, k, 1.0,
+                           EB, info, 1, PB);
+    else
+        hipLaunchKernelGGL((k_i8_slice_contig<I8_SCAP>), dim3(KC, gx), dim3(256), 0, st, b, (long long)ldb, n, k, 1.0,
+                           EB, info, 1, PB);
+
+    // ---- contract: passes over (digit block of A, digit block of B, k block); the device skips what the data does
+    // not need.  With one k pass and <= 8 digits on both sides the (0, 0) pass rounds and writes C itself.
+    const int force_multi = kpasses > 1 ? 1 : 0;
+    if (maybe_multi)
+        hipLaunchKernelGGL(k_i8_zero_w, dim3(c.num_cu * 8), dim3(256), 0, st, (long long)m * n * I8_NWG, info,
+                           force_multi, W);
+    const int dblocks = (scap + I8_SMAX - 1) / I8_SMAX;
+    for (int kp = 0; kp < kpasses; ++kp) {
+        const int kc0 = kp * (I8_KPASS / I8_T), kc1 = min(KC, kc0 + I8_KPASS / I8_T);
+        for (int pa_ = 0; pa_ < dblocks; ++pa_)
+            for (int pb_ = 0; pb_ < dblocks; ++pb_)
+                hipLaunchKernelGGL(k_gemm_i8, dim3(gy * gx), dim3(256), 0, st, m, n, KC, kc0, kc1, pa_ * I8_SMAX,
+                                   pb_ * I8_SMAX, PA, PB, info, EA, EB, beta, cmat, (long long)ldc, round_mode,
+                                   force_multi ? 0 : 1, W);
+    }
+    if (maybe_multi)
+        hipLaunchKernelGGL(k_i8_finish, dim3((unsigned)(((long long)m * n + 255) / 256)), dim3(256), 0, st, m, n, info,
+                           EA, EB, beta, cmat, (long long)ldc, round_mode, force_multi, W);
+    *launched = true;
+    *gate = info + INFO_PATH;
+    c.gemm_info_dev = info;
+    return hipGetLastError();
+}
+
+}  // namespace exb

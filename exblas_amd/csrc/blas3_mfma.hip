@@ -23,6 +23,7 @@
 // k_gemm is the ~30 VALU ops per product of the TwoProd+TwoSum chain against SA*SB MFMA-FMAs per product.
 #include "superacc.hip.h"
 #include "exblas_internal.h"
+#include "gemm_scan.hip.h"
 
 #include <type_traits>
 
@@ -44,111 +45,6 @@ constexpr int MF_BETA = 21;
 constexpr int MF_KP = 512;    // k-block over which MFMA partial sums stay exact
 constexpr int MF_KB = 16;  // workgroup tile: BM = 32*RT rows x BN = 32*CT columns (RT x CT MFMA tiles of 16x16 per wave)
 constexpr int MF_THREADS = 256;
-
-// info words written by the scan kernels
-enum { INFO_NEED_A = 0, INFO_NEED_B = 1, INFO_FLAGS = 2, INFO_EMIN = 3, INFO_EMAX = 4, INFO_WORDS = 8 };
-
-// ---------------------------------------------------------------------------------------------
-// scan: per vector (row of A' / column of B) the scale, and globally the number of bits to cover
-// ---------------------------------------------------------------------------------------------
-struct ScanAcc {
-    int emax, lsbmin;
-    unsigned bad;
-    __device__ __forceinline__ void init() { emax = -100000; lsbmin = 100000; bad = 0; }
-    __device__ __forceinline__ void add(double x)
-    {
-        const unsigned long long u = (unsigned long long)__double_as_longlong(x);
-        const unsigned be = (unsigned)(u >> 52) & 0x7ffu;
-        const unsigned long long frac = u & 0x000fffffffffffffull;
-        if (be == 0) {
-            if (frac) bad = 1;  // subnormal input: scalar path
-            return;             // zero
-        }
-        if (be == 0x7ffu) { bad = 1; return; }
-        const int e = (int)be - 1023;
-        const unsigned long long mant = frac | 0x0010000000000000ull;
-        const int lsb = e - 52 + __builtin_ctzll(mant);
-        emax = max(emax, e);
-        lsbmin = min(lsbmin, lsb);
-    }
-    __device__ __forceinline__ void merge(const ScanAcc &o)
-    {
-        emax = max(emax, o.emax);
-        lsbmin = min(lsbmin, o.lsbmin);
-        bad |= o.bad;
-    }
-};
-
-// Both scan kernels only fold their part of a vector into vmax[v] / vlsb[v] (atomicMax / atomicMin), so the
-// reduction dimension can be split over workgroups; k_scan_finish then derives the scale and the global needs.
-__device__ __forceinline__ void scan_publish(const ScanAcc &s, int *vmax, int *vlsb, int *info)
-{
-    if (s.emax > -50000) {
-        atomicMax(vmax, s.emax);
-        atomicMin(vlsb, s.lsbmin);
-    }
-    if (s.bad) atomicOr((unsigned *)&info[INFO_FLAGS], 1u);
-}
-
-// vectors whose elements are contiguous (stride 1 along the reduction): one workgroup per vector
-__global__ void __launch_bounds__(256) k_scan_contig(const double *__restrict__ p, long long ldv, int nvec, int len,
-                                                     double scale, int *vmax, int *vlsb, int *info)
-{
-    __shared__ ScanAcc red[256];
-    const int v = blockIdx.x;
-    if (v >= nvec) return;
-    ScanAcc s;
-    s.init();
-    const double *q = p + (long long)v * ldv;
-    for (int i = threadIdx.x; i < len; i += 256) s.add(scale * q[i]);
-    red[threadIdx.x] = s;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) red[threadIdx.x].merge(red[threadIdx.x + o]);
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) scan_publish(red[0], &vmax[v], &vlsb[v], info);
-}
-
-// vectors whose elements are strided by ldv (adjacent vectors are contiguous): one thread per vector and
-// per slice of the reduction dimension (blockIdx.y)
-__global__ void __launch_bounds__(256) k_scan_strided(const double *__restrict__ p, long long ldv, int nvec, int len,
-                                                      double scale, int *vmax, int *vlsb, int *info)
-{
-    const int v = blockIdx.x * 256 + threadIdx.x;
-    if (v >= nvec) return;
-    const int per = (len + gridDim.y - 1) / gridDim.y;
-    const int i0 = blockIdx.y * per, i1 = min(len, i0 + per);
-    ScanAcc s;
-    s.init();
-    for (int i = i0; i < i1; ++i) s.add(scale * p[(long long)i * ldv + v]);
-    scan_publish(s, &vmax[v], &vlsb[v], info);
-}
-
-__global__ void __launch_bounds__(256) k_scan_init(int nvec, int *vmax, int *vlsb)
-{
-    const int v = blockIdx.x * 256 + threadIdx.x;
-    if (v < nvec) {
-        vmax[v] = -100000;
-        vlsb[v] = 100000;
-    }
-}
-
-// vmax -> scale ea = emax + 1 (in place), and the global slice need / exponent range
-__global__ void __launch_bounds__(256) k_scan_finish(int nvec, int *vmax, const int *vlsb, int *info, int need_slot)
-{
-    const int v = blockIdx.x * 256 + threadIdx.x;
-    if (v >= nvec) return;
-    const int e = vmax[v];
-    if (e < -50000) {
-        vmax[v] = 0;
-        return;
-    }
-    vmax[v] = e + 1;
-    atomicMax(&info[need_slot], e + 1 - vlsb[v]);
-    atomicMin(&info[INFO_EMIN], e);
-    atomicMax(&info[INFO_EMAX], e);
-}
 
 // ---------------------------------------------------------------------------------------------
 // slicing: x = sum_p out[p] * 2^(ea - BETA*(p+1)) with integer digits out[p], exactly (the scan guarantees that x is
@@ -401,8 +297,10 @@ static void launch_mfma(int ta, int tb, int m, int n, int k, double alpha, const
                        b, (long long)ldb, beta, c, (long long)ldc, EA, EB);
 }
 
+// The fp64-slice path (exblas_set_gemm_path(3)): kept as the literal "MFMA_F64 panel contraction" and as an A/B partner
+// of the int8 path (blas3_i8.hip), which is what exgemm uses by default.
 // Returns true when the MFMA path ran; false -> caller uses the scalar kernel.  Synchronises the stream once
-// (the slice counts are read back on the host).
+// (the slice counts are read back on the host), so this path cannot be captured into a hipGraph.
 bool exgemm_try_mfma(Ctx &c, char transa, char transb, int m, int n, int k, double alpha, const double *a, int lda,
                      const double *b, int ldb, double beta, double *cmat, int ldc, hipStream_t st, hipError_t *err)
 {
@@ -413,9 +311,7 @@ bool exgemm_try_mfma(Ctx &c, char transa, char transb, int m, int n, int k, doub
     int *buf = (int *)workspace(c, sizeof(int) * (2 * ((size_t)m + n) + INFO_WORDS), st, err);
     if (!buf) return true;
     int *info = buf, *EA = buf + INFO_WORDS, *EB = EA + m, *LA = EB + n, *LB = LA + m;
-    const int init[INFO_WORDS] = {0, 0, 0, 100000, -100000, 0, 0, 0};
-    if ((*err = hipMemcpyAsync(info, init, sizeof(init), hipMemcpyHostToDevice, st)) != hipSuccess) return true;
-    hipLaunchKernelGGL(k_scan_init, dim3((m + n + 255) / 256), dim3(256), 0, st, m + n, EA, LA);  // EA|EB and LA|LB are contiguous
+    hipLaunchKernelGGL(k_scan_init, dim3((m + n + 255) / 256), dim3(256), 0, st, m + n, EA, LA, info);  // EA|EB and LA|LB are contiguous
     const int ysplit = k >= 2048 ? 32 : (k >= 256 ? 8 : 1);
     // rows of A' (reduction over l)
     if (!ta)

@@ -103,6 +103,7 @@ Ctx &ctx(int device, int layer)
             const Ctx &z = g_ctx[0][device];
             c.blocks_per_cu = z.blocks_per_cu; c.bpc_sum = z.bpc_sum; c.bpc_dot = z.bpc_dot; c.bpc_sa = z.bpc_sa;
             c.ngroups = z.ngroups; c.variant = z.variant; c.gemm_path = z.gemm_path;
+            c.gemm_max_slices = z.gemm_max_slices;
         }
         EXB_CHECK(hipMalloc(&c.gacc_all, 2 * sizeof(long long) * NL * c.ngroups));
         EXB_CHECK(hipMemset(c.gacc_all, 0, 2 * sizeof(long long) * NL * c.ngroups));
@@ -350,7 +351,45 @@ int exblas_set_accumulator_slot(int slot)
     return 0;
 }
 
-int exblas_last_gemm_slices(void) { return ctx(-1, g_last_layer[current_device()]).last_gemm_slices; }
+// out[0] = implementation of the most recent exgemm on this device (0 scalar kernel, 1 fp64 slices on MFMA-F64,
+// 2 int8 slices on the int8 matrix cores), out[1] / out[2] = digits (slices) of A / B, out[3..7] reserved.
+// The int8 path decides on the device: this call then synchronises the device and reads the decision back.
+int exblas_last_gemm_info(int *out)
+{
+    Ctx &c = ctx(-1, g_last_layer[current_device()]);
+    std::lock_guard<std::mutex> lk(c.mu);
+    for (int i = 0; i < 8; ++i) out[i] = 0;
+    if (c.gemm_info_dev) {
+        int h[8];
+        if (hipDeviceSynchronize() != hipSuccess) return -1;
+        if (hipMemcpy(h, c.gemm_info_dev, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        out[0] = h[7] == 2 ? 2 : 0;  // INFO_PATH
+        if (out[0] == 2) {
+            out[1] = h[5];           // INFO_SA
+            out[2] = h[6];           // INFO_SB
+        }
+    } else if (c.last_gemm_slices > 0) {
+        out[0] = 1;
+        out[1] = out[2] = c.last_gemm_slices;
+    }
+    return 0;
+}
+
+int exblas_last_gemm_slices(void)
+{
+    int v[8];
+    if (exblas_last_gemm_info(v) != 0) return -1;
+    return v[1] > v[2] ? v[1] : v[2];
+}
+
+void exblas_set_gemm_max_slices(int s)
+{
+    ctx(-1);
+    for_each_layer(current_device(), [&](Ctx &c) {
+        std::lock_guard<std::mutex> lk(c.mu);
+        c.gemm_max_slices = s;
+    });
+}
 
 void exblas_set_gemm_path(int mode)
 {

@@ -20,8 +20,13 @@ struct Ctx {
     int bpc_sa = 3;          // superaccumulator-only ExSUM (LDS-atomic bound; 3/CU: 6.65 TB/s, 2/CU: 6.0)
     int ngroups = 32;        // EXBLAS_NGROUPS: global group accumulators the blocks add into
     int variant = 0;         // tuning variant of the production kernels (exblas_set_tuning)
-    int last_gemm_slices = 0;  // 0: the last exgemm ran the scalar kernel; 2..4: MFMA path with that many slices
-    int gemm_path = 0;       // 0 auto (MFMA-F64 slices when the data qualifies), 1 scalar only, 2 MFMA for every fpe
+    // which ExGEMM implementation the last call used.  The int8 path decides on the device: gemm_info_dev then points
+    // at its info block (read lazily, with a synchronisation, by exblas_last_gemm_info); otherwise the host knows.
+    int last_gemm_slices = 0;  // host-decided paths: 0 scalar kernel; 2..4: fp64-slice MFMA path with that many slices
+    const int *gemm_info_dev = nullptr;
+    int gemm_path = 0;       // 0 / 2: int8 slices on the matrix cores when the data qualifies (decided on the device),
+                             // 1: scalar kernel only, 3: fp64 slices on MFMA-F64 (host-decided, synchronises)
+    int gemm_max_slices = 0; // 0 = default (16): digits per operand the int8 path reserves workspace for
     long long *gacc = nullptr;   // ACTIVE accumulator set: [ngroups][NL] int64, zero between calls
     unsigned *gflags = nullptr;  // non-finite input flags of the active set, zero between calls
     // two sets, so that the finalize of step i (side stream) can overlap the streaming kernel of step i+1
@@ -84,6 +89,9 @@ hipError_t exgemm_dispatch(Ctx &c, char transa, char transb, int m, int n, int k
 hipError_t extrsv_dispatch(Ctx &c, char uplo, char transa, char diag, int n, const double *a, int lda, double *x,
                            int incx, int fpe, int early_exit, int round_mode, hipStream_t st);
 
+hipError_t exgemm_i8(Ctx &c, char transa, char transb, int m, int n, int k, double alpha, const double *a, int lda,
+                     const double *b, int ldb, double beta, double *cmat, int ldc, int round_mode, hipStream_t st,
+                     bool *launched, const int **gate);
 bool exgemm_try_mfma(Ctx &c, char transa, char transb, int m, int n, int k, double alpha, const double *a, int lda,
                      const double *b, int ldb, double beta, double *cmat, int ldc, hipStream_t st, hipError_t *err);
 

@@ -73,10 +73,18 @@ const char *exblas_hip_version(void);
 /* Launch-geometry knobs for A/B measurements (<= 0 / < 0 leave a value unchanged): resident blocks per CU
  * of the streaming kernels, number of global group accumulators, kernel variant (0 = production). */
 int exblas_set_tuning(int blocks_per_cu, int ngroups, int variant);
-/* ExGEMM implementation: 0 = auto (error-free slices on MFMA-F64 for the expansion variants when the data
- * qualifies, scalar kernel otherwise), 1 = scalar kernel only, 2 = MFMA path for every fpe.  Same bits either way. */
+/* ExGEMM implementation.  0 (default; 2 is a synonym): error-free 8-bit slices on the int8 matrix cores
+ * (v_mfma_i32_32x32x32_i8) for every (fpe, early_exit) variant and both rounding modes whenever the data qualifies --
+ * decided on the device, the scalar kernel runs otherwise; 1 = scalar kernel only (TwoProd + expansions + one
+ * superaccumulator per output, the reference's own scheme); 3 = error-free 21-bit slices on MFMA-F64
+ * (v_mfma_f64_16x16x4_f64; host-decided: synchronises the stream, exact-rounding mode only).  Same bits on every path. */
 void exblas_set_gemm_path(int mode);
-/* which implementation the last exgemm used: 0 = scalar kernel, 2..4 = MFMA path with that many slices */
+/* digits per operand the int8 path may use (workspace: that many bytes per matrix entry); 0 = default 16 */
+void exblas_set_gemm_max_slices(int s);
+/* Which implementation the last exgemm on this device used: out[0] = 0 scalar kernel / 1 fp64 slices / 2 int8
+ * slices, out[1], out[2] = slices of A, B (out[1]*out[2] matrix multiply-adds per element pair).  Synchronises the
+ * device when the decision was taken there.  exblas_last_gemm_slices() = max(out[1], out[2]), 0 for the scalar kernel. */
+int exblas_last_gemm_info(int *out8);
 int exblas_last_gemm_slices(void);
 /* Makes the *_dev layer's workspace at least `bytes` large (see "Workspace and hipGraphs" above). */
 int exblas_reserve_workspace(size_t bytes);

@@ -101,34 +101,47 @@ def test_exgemm_trans_alpha_beta(ex, oracle):
             assert (_bits(c) == _bits(want)).all(), (ta, tb, alpha, beta)
 
 
+def gemm_info(lib):
+    """(path, slices of A, slices of B) of the last exgemm: path 0 scalar kernel, 1 fp64 slices, 2 int8 slices"""
+    import ctypes as C
+    v = (C.c_int * 8)()
+    assert lib.exblas_last_gemm_info(v) == 0
+    return v[0], v[1], v[2]
+
+
 @pytest.mark.parametrize("m,n,k", [(64, 64, 512), (130, 75, 1100), (16, 200, 33)])
-def test_exgemm_mfma_path_is_exact(ex, oracle, m, n, k):
-    """The MFMA-F64 slice path (blas3_mfma.hip) against the oracle and the scalar kernel, bit for bit."""
+def test_exgemm_slice_paths_are_exact(ex, oracle, m, n, k):
+    """The int8-slice path (blas3_i8.hip, default), the fp64-slice path (blas3_mfma.hip, mode 3) and the scalar
+    kernel (mode 1) against the oracle, bit for bit, with the digit counts each data family must take."""
     lib = ex.load_library()
     rng = np.random.default_rng(5)
+    # name: (A, B, 21-bit fp64 slices [0 = refused], int8 digits of A, of B)
     cases = {
-        "fpuniform_r10": (oracle.gen("fpuniform", m * k, 81, 10, 0), oracle.gen("fpuniform", k * n, 82, 10, 0), 3),
-        "signed_r20": (oracle.gen("fpuniform_signed", m * k, 83, 20, 10), oracle.gen("fpuniform_signed", k * n, 84, 20, 10), 4),
-        "naive": (oracle.gen("naive", m * k, 1), oracle.gen("naive", k * n, 1), 3),
-        "small_ints": (rng.integers(-1000, 1000, m * k).astype(np.float64), rng.integers(-1000, 1000, k * n).astype(np.float64), 2),
-        "wide_r60": (oracle.gen("fpuniform_signed", m * k, 85, 60, 30), oracle.gen("fpuniform_signed", k * n, 86, 60, 30), 0),
+        "fpuniform_r10": (oracle.gen("fpuniform", m * k, 81, 10, 0), oracle.gen("fpuniform", k * n, 82, 10, 0), 3, 8, 8),
+        "signed_r20": (oracle.gen("fpuniform_signed", m * k, 83, 20, 10), oracle.gen("fpuniform_signed", k * n, 84, 20, 10), 4, 10, 10),
+        "naive": (oracle.gen("naive", m * k, 1), oracle.gen("naive", k * n, 1), 3, 7, 7),
+        "small_ints": (rng.integers(-1000, 1000, m * k).astype(np.float64), rng.integers(-1000, 1000, k * n).astype(np.float64), 2, 2, 2),
+        "wide_r60": (oracle.gen("fpuniform_signed", m * k, 85, 60, 30), oracle.gen("fpuniform_signed", k * n, 86, 60, 30), 0, 15, 15),
     }
     try:
-        for name, (a, b, want_slices) in cases.items():
+        for name, (a, b, f64_slices, da, db) in cases.items():
             c0 = oracle.gen("fpuniform_signed", m * n, 87, 10, 5)
             want = oracle.exgemm("N", "N", m, n, k, 1.0, a, k, b, n, 1.0, c0, n, 0)
-            for path, fpe, ee in ((0, 8, True), (2, 0, False), (1, 8, True)):
+            for path, fpe, ee in ((0, 8, True), (0, 0, False), (3, 8, True), (1, 8, True)):
                 lib.exblas_set_gemm_path(path)
                 c = c0.copy()
                 ex.exgemm("N", "N", m, n, k, 1.0, a, k, b, n, 1.0, c, n, fpe, ee)
-                used = lib.exblas_last_gemm_slices()
-                assert (_bits(c) == _bits(want)).all(), (name, path, fpe, used, int((c != want).sum()))
-                if path != 1:
-                    assert used == want_slices, (name, path, used, want_slices)
+                info = gemm_info(lib)
+                assert (_bits(c) == _bits(want)).all(), (name, path, fpe, info, int((c != want).sum()))
+                if path == 0:
+                    assert info[0] == 2 and info[1] <= da and info[2] <= db and max(info[1], info[2]) >= max(da, db) - 1, \
+                        (name, info, da, db)
+                elif path == 3:
+                    assert info == ((1, f64_slices, f64_slices) if f64_slices else (0, 0, 0)), (name, info)
                 else:
-                    assert used == 0
-        # transposes / alpha / beta through the MFMA path
-        lib.exblas_set_gemm_path(2)
+                    assert info == (0, 0, 0)
+        # transposes / alpha / beta / leading dimensions through the int8 path, both rounding modes
+        lib.exblas_set_gemm_path(0)
         for ta, tb in (("N", "T"), ("T", "N"), ("T", "T")):
             lda = (m if ta == "T" else k) + 1
             ldb = (k if tb == "T" else n) + 2
@@ -136,13 +149,87 @@ def test_exgemm_mfma_path_is_exact(ex, oracle, m, n, k):
             b = oracle.gen("fpuniform_signed", (n if tb == "T" else k) * ldb, 92, 8, 4)
             c0 = oracle.gen("fpuniform_signed", m * (n + 3), 93, 8, 4)
             for alpha, beta in ((1.0, 1.0), (0.5, 0.0), (-1.25, 2.0)):
-                want = oracle.exgemm(ta, tb, m, n, k, alpha, a, lda, b, ldb, beta, c0, n + 3, 4, False)
-                c = c0.copy()
-                ex.exgemm(ta, tb, m, n, k, alpha, a, lda, b, ldb, beta, c, n + 3, 4, False)
-                assert lib.exblas_last_gemm_slices() >= 2
-                assert (_bits(c) == _bits(want)).all(), (ta, tb, alpha, beta)
+                for mode in (oracle.ROUND_EXACT, oracle.ROUND_REFERENCE):
+                    want = oracle.exgemm(ta, tb, m, n, k, alpha, a, lda, b, ldb, beta, c0, n + 3, 4, False, mode=mode)
+                    lib.exblas_set_round_mode(mode)
+                    c = c0.copy()
+                    ex.exgemm(ta, tb, m, n, k, alpha, a, lda, b, ldb, beta, c, n + 3, 4, False)
+                    assert gemm_info(lib)[0] == 2
+                    assert (_bits(c) == _bits(want)).all(), (ta, tb, alpha, beta, mode)
     finally:
         lib.exblas_set_gemm_path(0)
+        lib.exblas_set_round_mode(0)
+
+
+def test_exgemm_i8_multi_pass(ex, oracle):
+    """More than 8 digits per operand (2 x 2 digit-block passes into the 320-bit accumulators) and k > 8192 (k passes):
+    ill-conditioned operands (init_ill_cond, c = 1e32: 14 digits), negative-heavy reference rounding, odd shapes."""
+    lib = ex.load_library()
+    try:
+        for (m, n, k, kind, p0, p1) in ((70, 66, 300, "ill_cond", 1e32, 0.0), (33, 65, 9000, "fpuniform_signed", 10, 0),
+                                        (40, 40, 8300, "ill_cond", 1e16, 0.0), (129, 64, 64, "fpuniform_signed", 50, 25)):
+            a = oracle.gen(kind, m * k, 31, p0, p1)
+            b = oracle.gen(kind, k * n, 32, p0, p1)
+            c0 = oracle.gen("fpuniform_signed", m * n, 33, 10, 5)
+            for mode in (oracle.ROUND_EXACT, oracle.ROUND_REFERENCE):
+                want = oracle.exgemm("N", "N", m, n, k, 1.0, a, k, b, n, 1.0, c0, n, 0, mode=mode)
+                lib.exblas_set_round_mode(mode)
+                c = c0.copy()
+                ex.exgemm("N", "N", m, n, k, 1.0, a, k, b, n, 1.0, c, n, 8, True)
+                info = gemm_info(lib)
+                assert info[0] == 2 and (max(info[1], info[2]) > 8 or k > 8192), (kind, info)
+                assert (_bits(c) == _bits(want)).all(), (m, n, k, kind, mode, info, int((c != want).sum()))
+        # capacity knob: with at most 8 digits reserved, 14-digit data must take the scalar kernel -- same bits
+        lib.exblas_set_round_mode(0)
+        lib.exblas_set_gemm_max_slices(8)
+        m, n, k = 48, 48, 200
+        a, b = oracle.gen("ill_cond", m * k, 41, 1e32), oracle.gen("ill_cond", k * n, 42, 1e32)
+        want = oracle.exgemm("N", "N", m, n, k, 1.0, a, k, b, n, 0.0, np.zeros(m * n), n, 0)
+        c = np.zeros(m * n)
+        ex.exgemm("N", "N", m, n, k, 1.0, a, k, b, n, 0.0, c, n, 8, True)
+        assert gemm_info(lib)[0] == 0 and (_bits(c) == _bits(want)).all()
+    finally:
+        lib.exblas_set_gemm_max_slices(0)
+        lib.exblas_set_round_mode(0)
+
+
+def test_exgemm_is_stream_ordered_and_capturable(ex, oracle):
+    """exblas_exgemm_dev is a pure sequence of launches (slice counts and the path are decided on the device): it can
+    be captured into a hipGraph and replayed on new data -- including data that takes a different path on replay."""
+    import torch
+    lib = ex.load_library()
+    m, n, k = 192, 160, 320
+    A = ex.gen_dev("fpuniform", m * k, 51, 10, 0)
+    B = ex.gen_dev("fpuniform", k * n, 52, 10, 0)
+    C = torch.zeros(m * n, dtype=torch.float64, device="cuda")
+    ex.exgemm_dev("N", "N", m, n, k, 1.0, A, k, B, n, 0.0, C, n, 8, True)    # sizes the workspace outside the capture
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            ex.exgemm_dev("N", "N", m, n, k, 1.0, A, k, B, n, 0.0, C, n, 8, True)
+    datasets = [("fpuniform", 10, 0), ("ill_cond", 1e32, 0), ("naive", 0, 0), ("lognormal", 0.0, 40.0)]
+    for kind, p0, p1 in datasets:                # int8 x 8 digits, int8 x 14 digits (multi-pass), 7 digits, scalar kernel
+        A.copy_(ex.gen_dev(kind, m * k, 61, p0, p1))
+        B.copy_(ex.gen_dev(kind, k * n, 62, p0, p1))
+        C.fill_(-1.0)
+        g.replay()
+        torch.cuda.synchronize()
+        want = oracle.exgemm("N", "N", m, n, k, 1.0, A.cpu().numpy(), k, B.cpu().numpy(), n, 0.0, np.zeros(m * n), n, 0)
+        assert (_bits(C.cpu().numpy()) == _bits(want)).all(), kind
+    assert gemm_info(lib)[0] == 0                # the last data set (log-normal, sigma 40) took the scalar kernel
+    # growing the workspace during a capture is refused with an error instead of reallocating under the graph
+    big = 1024
+    Ab = ex.gen_dev("fpuniform", big * big, 53, 10, 0)
+    Cb = torch.zeros(big * big, dtype=torch.float64, device="cuda")
+    lib.exblas_release_retired_workspaces()
+    g2 = torch.cuda.CUDAGraph()
+    with pytest.raises(RuntimeError):
+        with torch.cuda.stream(s):
+            with torch.cuda.graph(g2, stream=s):
+                ex.exgemm_dev("N", "N", big, big, big, 1.0, Ab, big, Ab, big, 0.0, Cb, big, 8, True)
+    torch.cuda.synchronize()
 
 
 def test_standalone_cpp_gemv_gemm_caller(ex):
@@ -218,8 +305,9 @@ def same_bits(x, y):
 
 
 def test_exgemm_mfma_fallbacks(ex, oracle):
-    """Inputs the MFMA slice path must refuse (it then runs the scalar kernel): subnormals, Inf/NaN, huge exponents,
-    an all-zero operand; plus rows/columns of zeros and signed zeros inside the fast path.  Always the oracle's bits."""
+    """Inputs the int8 slice path must refuse ON THE DEVICE (the predicated scalar kernel then does the work):
+    subnormals, Inf/NaN, huge / tiny exponents; plus all-zero operands, rows/columns of zeros and signed zeros inside
+    the fast path.  Always the oracle's bits."""
     lib = ex.load_library()
     m, n, k = 48, 40, 96
     base_a = oracle.gen("fpuniform_signed", m * k, 71, 8, 4)
@@ -237,8 +325,8 @@ def test_exgemm_mfma_fallbacks(ex, oracle):
             want = np.where(np.isfinite(ieee), want, ieee)
         c = c0.copy()
         ex.exgemm("N", "N", m, n, k, 1.0, a, k, b, n, 0.0, c, n, 8, True)
-        used = lib.exblas_last_gemm_slices()
-        assert want_fast is None or (used >= 2) == want_fast, used
+        used = gemm_info(lib)
+        assert want_fast is None or (used[0] == 2) == want_fast, used
         ok = (_bits(c) == _bits(want)) | (np.isnan(c) & np.isnan(want))
         assert ok.all(), np.nonzero(~ok)[0][:5]
 
@@ -248,9 +336,11 @@ def test_exgemm_mfma_fallbacks(ex, oracle):
     run(a, base_b, False)                                  # Inf
     b = base_b.copy(); b[3] = np.nan
     run(base_a, b, False)                                  # NaN
-    run(base_a * 2.0**500, base_b, False)                  # exponents outside +-400
-    run(base_a, np.zeros(k * n), None)                     # all-zero operand: either path, exact zeros
-    run(np.zeros(m * k), np.zeros(k * n), False)           # nothing but zeros: scalar path
+    run(base_a * 2.0**500, base_b, False)                  # exponents outside +-300
+    run(base_a * 2.0**-305, base_b, False)
+    run(base_a * 2.0**280, base_b * 2.0**280, True)        # inside: products up to 2^570, still exact and normal
+    run(base_a, np.zeros(k * n), True)                     # all-zero operand: one all-zero digit plane, exact zeros
+    run(np.zeros(m * k), np.zeros(k * n), True)            # nothing but zeros
     a = base_a.copy().reshape(m, k); a[3, :] = 0.0; a[10, ::2] = -0.0
     b = base_b.copy().reshape(k, n); b[:, 7] = 0.0
     run(a.reshape(-1), b.reshape(-1), True)                # zero row / zero column / signed zeros: fast path
@@ -268,21 +358,31 @@ def test_gemv_gemm_randomized_soak(ex):
     assert r.returncode == 0 and "0 mismatches" in r.stdout, (r.stdout[-3000:], r.stderr[-2000:])
 
 
-def test_exgemm_mfma_mixed_digit_counts(ex, oracle):
-    """operands that need different numbers of 21-bit digits (A: 16-bit integers times powers of two -> 2 digits,
-    B: full 53-bit mantissas over 2^10 -> 3) run the 2x3 / 3x2 instantiations: same bits as the oracle"""
+def test_exgemm_mixed_digit_counts(ex, oracle):
+    """operands that need different numbers of digits (A: 16-bit integers times powers of two, B: full 53-bit
+    mantissas over 2^10) cost sa*sb matrix multiply-adds per element pair, not max^2: same bits as the oracle"""
     lib = ex.load_library()
     rng = np.random.default_rng(5)
     m, n, k = 96, 130, 700
     small = rng.integers(-30000, 30001, size=m * k).astype(np.float64) * 2.0 ** rng.integers(-3, 4, size=m * k)
     full = oracle.gen("fpuniform_signed", k * n, 77, 10, 0)
     c0 = oracle.gen("fpuniform_signed", m * n, 78, 10, 0)
-    for a, b, mm, nn in ((small, full, m, n), (full[:n * k], small[:k * m], n, m)):
-        want = oracle.exgemm("N", "N", mm, nn, k, 1.0, a, k, b, nn, 1.0, c0[:mm * nn], nn, 0)
-        c = c0[:mm * nn].copy()
-        ex.exgemm("N", "N", mm, nn, k, 1.0, a, k, b, nn, 1.0, c, nn, 8, True)
-        assert lib.exblas_last_gemm_slices() == 3
-        assert (_bits(c) == _bits(want)).all()
+    try:
+        for a, b, mm, nn, swap in ((small, full, m, n, False), (full[:n * k], small[:k * m], n, m, True)):
+            want = oracle.exgemm("N", "N", mm, nn, k, 1.0, a, k, b, nn, 1.0, c0[:mm * nn], nn, 0)
+            for path in (0, 3):
+                lib.exblas_set_gemm_path(path)
+                c = c0[:mm * nn].copy()
+                ex.exgemm("N", "N", mm, nn, k, 1.0, a, k, b, nn, 1.0, c, nn, 8, True)
+                info = gemm_info(lib)
+                if path == 0:
+                    da, db = (info[2], info[1]) if swap else (info[1], info[2])
+                    assert info[0] == 2 and da <= 4 and db == 8, info
+                else:
+                    assert info == (1, 3, 3), info
+                assert (_bits(c) == _bits(want)).all(), (path, swap)
+    finally:
+        lib.exblas_set_gemm_path(0)
 
 
 def test_expansion_sizes_above_8_gemv_gemm(ex, oracle):
