@@ -36,6 +36,7 @@ C_ABI_SYMBOLS = [
     "exblas_comm_destroy", "exblas_comm_rank", "exblas_comm_size", "exblas_shard_range",
     "exblas_exsum_allreduce_dev", "exblas_exdot_allreduce_dev", "exblas_allreduce_finish_dev",
     "exblas_exgemv_sharded_dev", "exblas_exgemm_sharded_dev", "exblas_last_gemm_info", "exblas_set_gemm_max_slices",
+    "exblas_set_host_devices",
 ]
 
 # host-transport callback types of include/exblas_hip.h
@@ -111,6 +112,7 @@ def load_library():
     L.exblas_exgemv.argtypes = [C.c_char, i32, i32, dbl, vp, i32, i32, vp, i32, i32, dbl, vp, i32, i32, i32, i32]
     L.exblas_exgemm.argtypes = [C.c_char, C.c_char, i32, i32, i32, dbl, vp, i32, vp, i32, dbl, vp, i32, i32, i32]
     L.exblas_reserve_workspace.argtypes = [C.c_size_t]
+    L.exblas_set_host_devices.argtypes = [i32, C.POINTER(C.c_int)]
     L.exblas_last_gemm_info.argtypes = [C.POINTER(C.c_int)]
     L.exblas_set_gemm_max_slices.argtypes = [i32]
     L.exblas_set_gemm_max_slices.restype = None

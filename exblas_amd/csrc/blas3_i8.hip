@@ -49,7 +49,7 @@ constexpr int I8_KPASS = 8192;   // k per pass: 8192 * 8 pairs * 2^14 = 2^30 < 2
 constexpr int I8_NWG = 5;        // 64-bit words of the per-entry accumulator in global memory (multi-pass)
 constexpr int I8_ERANGE = 300;   // |exponent| bound of the operands: keeps every rounded result a normal double
 
-enum { INFO_SA = 5, INFO_SB = 6, INFO_PATH = 7 };   // extends the scan's info block (INFO_WORDS == 8)
+enum { INFO_SA = 5, INFO_SB = 6, INFO_PATH = 7, INFO_BS = 8, INFO_EXACT = 9 };   // extends the scan's info block
 enum { PATH_SCALAR = 0, PATH_I8 = 2 };
 
 template <int B, int E, class F>
@@ -76,9 +76,25 @@ __global__ void k_i8_decide(int *info, int scap)
     sa = sa < 1 ? 1 : sa;
     sb = sb < 1 ? 1 : sb;
     if (sa > scap || sb > scap) path = PATH_SCALAR;
+    // Digit blocks.  A pass contracts bs x bs digit pairs with 2 bs - 1 accumulator tiles per wave (bs <= 8).
+    // Operands of (nearly) equal width -- the usual case: both come from one distribution -- are padded with zero
+    // digits to a common count that splits into equal blocks, so that the fully unrolled, software-pipelined pass body
+    // for that block size runs (i8_pass_exact); anything else takes 8 x 8 blocks through the generic body.
+    int bs = I8_SMAX, exact = 0;
+    const int hi = sa > sb ? sa : sb, lo = sa > sb ? sb : sa;
+    if (lo >= hi - 1 && hi >= 4) {
+        const int padded = hi <= I8_SMAX ? hi : 2 * ((hi + 1) / 2);
+        if (padded <= scap) {
+            sa = sb = padded;
+            bs = padded <= I8_SMAX ? padded : padded / 2;
+            exact = 1;
+        }
+    }
     info[INFO_SA] = sa;
     info[INFO_SB] = sb;
     info[INFO_PATH] = path;
+    info[INFO_BS] = bs;
+    info[INFO_EXACT] = exact;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -332,32 +348,210 @@ __device__ __forceinline__ void tile_of_block(int bid, int nbid, int gy, int gx,
     *tx = sc * SC + cx;
 }
 
-// One pass: C block (64 x 64 per workgroup) += digits [ta0, ta0+8) of A  x  digits [tb0, tb0+8) of B over k chunks
-// [kc0, kc1).  single != 0: this pass is the whole product -> round and write C; else add into the global accumulator.
-__global__ void __launch_bounds__(256, 1) k_gemm_i8(int m, int n, int KC, int kc0, int kc1, int ta0, int tb0,
-                                                    const signed char *__restrict__ PA,
-                                                    const signed char *__restrict__ PB, const int *__restrict__ info,
-                                                    const int *__restrict__ EA, const int *__restrict__ EB,
-                                                    double beta, double *__restrict__ c, long long ldc, int round_mode,
-                                                    int allow_single, unsigned long long *__restrict__ W)
+// ---- pieces shared by the pass bodies ------------------------------------------------------------------------
+struct PassArgs {
+    int m, n, KC, kc0, kc1, ta0, tb0;
+    const signed char *PA, *PB;
+    const int *EA, *EB;
+    double beta;
+    double *c;
+    long long ldc;
+    int round_mode;
+    unsigned long long *W;
+    int sa_all, sb_all;  // digits of the whole operands (plane strides, units)
+    bool single;         // this pass is the whole product: round and write C
+};
+
+// epilogue: G group sums -> one 192-bit integer per entry; C layout of the 32x32 MFMA:
+// col = lane & 31, row = 8 * (r / 4) + 4 * (lane / 32) + (r % 4)
+template <int G>
+__device__ __forceinline__ void i8_epilogue(const PassArgs &a, const v16i_t (&acc)[G], int ty, int tx, int wr, int wc)
 {
-    constexpr int G = 2 * I8_SMAX - 1;
-    __shared__ v4i_t lds[2][2 * I8_SMAX * (I8_TILE / 16)];  // [buffer][A planes | B planes][256 x 16 B]: 128 KiB
-    if (info[INFO_PATH] != PATH_I8) return;
-    const int sa_all = info[INFO_SA], sb_all = info[INFO_SB];
-    if (ta0 >= sa_all || tb0 >= sb_all) return;
-    const int sa = min(I8_SMAX, sa_all - ta0), sb = min(I8_SMAX, sb_all - tb0);
-    const bool single = allow_single && sa_all <= I8_SMAX && sb_all <= I8_SMAX;
+    const int lane = threadIdx.x & 63, half = lane >> 5;
+    const int gj = tx * I8_T + wc + (lane & 31);
+    const int ebj = gj < a.n ? a.EB[gj] : 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        unsigned long long w3[3] = {0ull, 0ull, 0ull};
+        static_for_i8<0, G>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            wide_add_c<3, 8 * g>(w3, (long long)acc[g][r]);
+        });
+        const int gi = ty * I8_T + wr + 8 * (r >> 2) + 4 * half + (r & 3);
+        if (gi < a.m && gj < a.n) {
+            // unit of this pass's integer: 2^(ua + ub) * 256^(ta0 + tb0), ua = ea - 8 sa + 2
+            const int u0 = a.EA[gi] - 8 * a.sa_all + 2 + ebj - 8 * a.sb_all + 2;
+            if (a.single) {
+                const double sres = a.round_mode ? wide_round_reference<3>(w3, u0 + 8 * (a.ta0 + a.tb0))
+                                                 : wide_round_n<3>(w3, u0 + 8 * (a.ta0 + a.tb0));
+                double *cij = a.c + (long long)gi * a.ldc + gj;
+                *cij = (a.beta == 0.0) ? sres : a.beta * (*cij) + sres;
+            } else {
+                unsigned long long *wg = a.W + ((size_t)gi * a.n + gj) * I8_NWG;
+                unsigned long long acc5[I8_NWG];
+#pragma unroll
+                for (int i = 0; i < I8_NWG; ++i) acc5[i] = wg[i];
+                wide_add_v<I8_NWG>(acc5, w3, 8 * (a.ta0 + a.tb0));
+#pragma unroll
+                for (int i = 0; i < I8_NWG; ++i) wg[i] = acc5[i];
+            }
+        }
+    }
+}
+
+// LDS of one workgroup: [buffer][A planes | B planes][256 x 16 B] = 128 KiB
+typedef v4i_t (*LdsBuf)[2 * I8_SMAX * (I8_TILE / 16)];
+
+// wait for this wave's LDS traffic, then the workgroup barrier -- without the vmcnt(0) of __syncthreads(): the global
+// loads of the chunk after next stay in flight across it
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// EXACT body: SA = SB = B digits in this pass, everything unrolled, software-pipelined:
+//   per k chunk (64 bytes = two MFMA k-steps) a wave issues 2 x B*B MFMAs; the fragments of a k-step are read from LDS
+//   into one of two register sets while the MFMAs of the previous k-step run; the global loads of chunk kc+2 are issued
+//   right after the registers of chunk kc+1 have been stored to the other LDS buffer, i.e. a full chunk (~4000 cycles)
+//   ahead; one barrier per chunk.
+template <int B>
+__device__ __forceinline__ void i8_pass_exact(const PassArgs &a, LdsBuf lds)
+{
+    constexpr int G = 2 * B - 1;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int gy = (m + I8_T - 1) / I8_T, gx = (n + I8_T - 1) / I8_T;
+    const int gy = (a.m + I8_T - 1) / I8_T, gx = (a.n + I8_T - 1) / I8_T;
     int ty, tx;
     tile_of_block(blockIdx.x, gridDim.x, gy, gx, &ty, &tx);
     const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
+    const signed char *pa = a.PA + ((size_t)ty * a.KC * a.sa_all + a.ta0) * I8_TILE + (size_t)tid * 16;
+    const signed char *pb = a.PB + ((size_t)tx * a.KC * a.sb_all + a.tb0) * I8_TILE + (size_t)tid * 16;
+    const size_t stride_a = (size_t)a.sa_all * I8_TILE, stride_b = (size_t)a.sb_all * I8_TILE;
 
-    // tile streams: [tile][kc][plane][4 KiB]; this thread moves bytes [16 tid, 16 tid + 16) of every plane
-    const signed char *pa = PA + ((size_t)ty * KC * sa_all + ta0) * I8_TILE + (size_t)tid * 16;
-    const signed char *pb = PB + ((size_t)tx * KC * sb_all + tb0) * I8_TILE + (size_t)tid * 16;
-    const size_t stride_a = (size_t)sa_all * I8_TILE, stride_b = (size_t)sb_all * I8_TILE;
+    v4i_t ra[B], rb[B];
+    auto gload = [&](int kc) {
+#pragma unroll
+        for (int p = 0; p < B; ++p) ra[p] = *(const v4i_t *)(pa + kc * stride_a + (size_t)p * I8_TILE);
+#pragma unroll
+        for (int q = 0; q < B; ++q) rb[q] = *(const v4i_t *)(pb + kc * stride_b + (size_t)q * I8_TILE);
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < B; ++p) lds[buf][p * 256 + tid] = ra[p];
+#pragma unroll
+        for (int q = 0; q < B; ++q) lds[buf][(I8_SMAX + q) * 256 + tid] = rb[q];
+    };
+    const int arow = wr + (lane & 31), brow = wc + (lane & 31), half = lane >> 5;
+    int aoff[2], boff[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        aoff[ks] = tile_off(arow, (2 * ks + half) * 16) >> 4;
+        boff[ks] = tile_off(brow, (2 * ks + half) * 16) >> 4;
+    }
+    auto fload = [&](int buf, int ks, v4i_t (&fa)[B], v4i_t (&fb)[B]) {
+#pragma unroll
+        for (int q = 0; q < B; ++q) fb[q] = lds[buf][(I8_SMAX + q) * 256 + boff[ks]];
+#pragma unroll
+        for (int p = 0; p < B; ++p) fa[p] = lds[buf][p * 256 + aoff[ks]];
+    };
+    v16i_t acc[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[g][r] = 0;
+    auto contract = [&](const v4i_t (&fa)[B], const v4i_t (&fb)[B]) {
+#pragma unroll
+        for (int p = 0; p < B; ++p)
+#pragma unroll
+            for (int q = 0; q < B; ++q)
+                acc[p + q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[p], fb[q], acc[p + q], 0, 0, 0);
+    };
+
+    // Instruction order inside a k-step (a wave issues in order, and an MFMA only keeps the matrix pipe busy while the
+    // NEXT instruction is another MFMA or something cheap): after every NM MFMAs one LDS write (chunk kc+1 -> other
+    // buffer), one global load (chunk kc+2 -> staging registers) and one LDS read (fragments of the next k-step).
+    // The loop body is branch-free -- past the last chunk the loads and stores repeat the last chunk into a buffer
+    // nobody reads -- so each half of it is ONE scheduling region the group barriers below can order.
+    constexpr int NMEM = 2 * B;                              // memory instructions of each kind per k-step
+    // k-step 0 carries 3 * NMEM memory instructions, k-step 1 NMEM: one per MFMA gap (an MFMA leaves 24 of its 32
+    // cycles of issue time to other instructions; a ds_write_b128 takes 13 of them), the remaining MFMAs back to back
+    auto interleave_full = [&]() {
+        constexpr int REST = B * B - 3 * NMEM;               // B >= 6: >= 0
+        constexpr int PER = REST > 0 ? REST / NMEM : 0, EXTRA = REST > 0 ? REST % NMEM : 0;
+        static_for_i8<0, NMEM>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            if constexpr (B * B >= 3 * NMEM) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // DS write
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+                __builtin_amdgcn_sched_group_barrier(0x008, 1 + PER + (i < EXTRA ? 1 : 0), 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+            } else {  // fewer MFMAs than memory instructions (B = 4, 5): several memory instructions per gap
+                constexpr int NM = (B * B + NMEM - 1) / NMEM;
+                __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+        });
+    };
+    auto interleave_reads = [&]() {
+        constexpr int PER = B * B / NMEM, EXTRA = B * B % NMEM;
+        static_for_i8<0, NMEM>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            __builtin_amdgcn_sched_group_barrier(0x008, PER + (i < EXTRA ? 1 : 0), 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        });
+    };
+    auto clampk = [&](int kc) { return kc < a.kc1 ? kc : a.kc1 - 1; };
+
+    v4i_t fa0[B], fb0[B], fa1[B], fb1[B];
+    gload(a.kc0);
+    lstore(0);
+    gload(clampk(a.kc0 + 1));
+    lds_barrier();
+    fload(0, 0, fa0, fb0);
+    for (int kc = a.kc0; kc < a.kc1; ++kc) {
+        const int buf = (kc - a.kc0) & 1;
+        // k-step 0.  The other buffer was last read (k-step 1 of the previous chunk) before the previous barrier.
+        // The three memory streams are written interleaved in the source as well: the compiler must assume that an
+        // LDS write and an LDS read may alias (one array, dynamic buffer index) and keeps their relative order.
+        {
+            const int kn = clampk(kc + 2);
+#pragma unroll
+            for (int i = 0; i < NMEM; ++i) {
+                if (i < B) {
+                    lds[buf ^ 1][i * 256 + tid] = ra[i];
+                    ra[i] = *(const v4i_t *)(pa + kn * stride_a + (size_t)i * I8_TILE);
+                    fb1[i] = lds[buf][(I8_SMAX + i) * 256 + boff[1]];
+                } else {
+                    lds[buf ^ 1][(I8_SMAX + i - B) * 256 + tid] = rb[i - B];
+                    rb[i - B] = *(const v4i_t *)(pb + kn * stride_b + (size_t)(i - B) * I8_TILE);
+                    fa1[i - B] = lds[buf][(i - B) * 256 + aoff[1]];
+                }
+            }
+        }
+        contract(fa0, fb0);
+        interleave_full();
+        lds_barrier();
+        // k-step 1, with the fragments of the next chunk's k-step 0 arriving from the buffer just completed
+        fload(buf ^ 1, 0, fa0, fb0);
+        contract(fa1, fb1);
+        interleave_reads();
+    }
+    i8_epilogue<G>(a, acc, ty, tx, wr, wc);
+}
+
+// GENERIC body: up to 8 x 8 digits in this pass, counts known at run time only; digit pairs beyond (sa, sb) are skipped
+// by wave-uniform scalar branches.  Serves operand pairs whose digit counts differ by more than one.
+__device__ __forceinline__ void i8_pass_generic(const PassArgs &a, int sa, int sb, LdsBuf lds)
+{
+    constexpr int G = 2 * I8_SMAX - 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int gy = (a.m + I8_T - 1) / I8_T, gx = (a.n + I8_T - 1) / I8_T;
+    int ty, tx;
+    tile_of_block(blockIdx.x, gridDim.x, gy, gx, &ty, &tx);
+    const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
+    const signed char *pa = a.PA + ((size_t)ty * a.KC * a.sa_all + a.ta0) * I8_TILE + (size_t)tid * 16;
+    const signed char *pb = a.PB + ((size_t)tx * a.KC * a.sb_all + a.tb0) * I8_TILE + (size_t)tid * 16;
+    const size_t stride_a = (size_t)a.sa_all * I8_TILE, stride_b = (size_t)a.sb_all * I8_TILE;
 
     v4i_t ra[I8_SMAX], rb[I8_SMAX];
     auto gload = [&](int kc) {
@@ -376,14 +570,11 @@ __global__ void __launch_bounds__(256, 1) k_gemm_i8(int m, int n, int KC, int kc
         for (int q = 0; q < I8_SMAX; ++q)
             if (q < sb) lds[buf][(I8_SMAX + q) * 256 + tid] = rb[q];
     };
-
     v16i_t acc[G];
 #pragma unroll
     for (int g = 0; g < G; ++g)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[g][r] = 0;
-
-    // fragment addresses (in 16-byte units inside a plane): lane -> row (lane & 31), chunk (2 ks + lane / 32), swizzled
     const int arow = wr + (lane & 31), brow = wc + (lane & 31), half = lane >> 5;
     int aoff[2], boff[2];
 #pragma unroll
@@ -391,13 +582,12 @@ __global__ void __launch_bounds__(256, 1) k_gemm_i8(int m, int n, int KC, int kc
         aoff[ks] = tile_off(arow, (2 * ks + half) * 16) >> 4;
         boff[ks] = tile_off(brow, (2 * ks + half) * 16) >> 4;
     }
-
-    gload(kc0);
+    gload(a.kc0);
     lstore(0);
     __syncthreads();
-    for (int kc = kc0; kc < kc1; ++kc) {
-        const int buf = (kc - kc0) & 1;
-        if (kc + 1 < kc1) gload(kc + 1);  // in flight while this chunk is contracted
+    for (int kc = a.kc0; kc < a.kc1; ++kc) {
+        const int buf = (kc - a.kc0) & 1;
+        if (kc + 1 < a.kc1) gload(kc + 1);  // in flight while this chunk is contracted
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             v4i_t fa[I8_SMAX], fb[I8_SMAX];
@@ -416,40 +606,46 @@ __global__ void __launch_bounds__(256, 1) k_gemm_i8(int m, int n, int KC, int kc
                 }
             }
         }
-        if (kc + 1 < kc1) lstore(buf ^ 1);  // that buffer was last read one iteration ago, before the barrier below
+        if (kc + 1 < a.kc1) lstore(buf ^ 1);  // that buffer was last read one iteration ago, before the barrier below
         __syncthreads();
     }
+    i8_epilogue<G>(a, acc, ty, tx, wr, wc);
+}
 
-    // ---- epilogue: 15 group sums -> one 192-bit integer per entry; C layout of the 32x32 MFMA:
-    // col = lane & 31, row = 8 * (r / 4) + 4 * (lane / 32) + (r % 4)
-    const int gj = tx * I8_T + wc + (lane & 31);
-    const int ebj = gj < n ? EB[gj] : 0;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        unsigned long long w3[3] = {0ull, 0ull, 0ull};
-        static_for_i8<0, G>([&](auto gc) {
-            constexpr int g = decltype(gc)::value;
-            wide_add_c<3, 8 * g>(w3, (long long)acc[g][r]);
-        });
-        const int gi = ty * I8_T + wr + 8 * (r >> 2) + 4 * half + (r & 3);
-        if (gi < m && gj < n) {
-            // unit of this pass's integer: 2^(ua + ub) * 256^(ta0 + tb0), ua = ea - 8 sa + 2
-            const int u0 = EA[gi] - 8 * sa_all + 2 + ebj - 8 * sb_all + 2;
-            if (single) {
-                const double s = round_mode ? wide_round_reference<3>(w3, u0 + 8 * (ta0 + tb0))
-                                            : wide_round_n<3>(w3, u0 + 8 * (ta0 + tb0));
-                double *cij = c + (long long)gi * ldc + gj;
-                *cij = (beta == 0.0) ? s : beta * (*cij) + s;
-            } else {
-                unsigned long long *wg = W + ((size_t)gi * n + gj) * I8_NWG;
-                unsigned long long acc5[I8_NWG];
-#pragma unroll
-                for (int i = 0; i < I8_NWG; ++i) acc5[i] = wg[i];
-                wide_add_v<I8_NWG>(acc5, w3, 8 * (ta0 + tb0));
-#pragma unroll
-                for (int i = 0; i < I8_NWG; ++i) wg[i] = acc5[i];
-            }
+// One pass: C block (64 x 64 per workgroup) += digits [ta0, ta0+bs) of A  x  digits [tb0, tb0+bs) of B over k chunks
+// [kc0, kc1), where (ta0, tb0) = (ia, ib) * bs and bs is the digit block size the device chose (k_i8_decide).
+// allow_single: with one pass in all this launch rounds and writes C itself; otherwise it adds into W.
+__global__ void __launch_bounds__(256, 1) k_gemm_i8(int m, int n, int KC, int kc0, int kc1, int ia, int ib,
+                                                    const signed char *__restrict__ PA,
+                                                    const signed char *__restrict__ PB, const int *__restrict__ info,
+                                                    const int *__restrict__ EA, const int *__restrict__ EB,
+                                                    double beta, double *__restrict__ c, long long ldc, int round_mode,
+                                                    int allow_single, unsigned long long *__restrict__ W)
+{
+    __shared__ v4i_t lds[2][2 * I8_SMAX * (I8_TILE / 16)];
+    if (info[INFO_PATH] != PATH_I8) return;
+    PassArgs a;
+    a.sa_all = info[INFO_SA];
+    a.sb_all = info[INFO_SB];
+    const int bs = info[INFO_BS];
+    a.ta0 = ia * bs;
+    a.tb0 = ib * bs;
+    if (a.ta0 >= a.sa_all || a.tb0 >= a.sb_all) return;
+    const int sa = min(bs, a.sa_all - a.ta0), sb = min(bs, a.sb_all - a.tb0);
+    a.m = m; a.n = n; a.KC = KC; a.kc0 = kc0; a.kc1 = kc1;
+    a.PA = PA; a.PB = PB; a.EA = EA; a.EB = EB;
+    a.beta = beta; a.c = c; a.ldc = ldc; a.round_mode = round_mode; a.W = W;
+    a.single = allow_single && a.sa_all <= bs && a.sb_all <= bs;
+    if (info[INFO_EXACT]) {  // sa == sb == bs in every pass
+        switch (bs) {
+        case 4: i8_pass_exact<4>(a, lds); break;
+        case 5: i8_pass_exact<5>(a, lds); break;
+        case 6: i8_pass_exact<6>(a, lds); break;
+        case 7: i8_pass_exact<7>(a, lds); break;
+        default: i8_pass_exact<8>(a, lds); break;
         }
+    } else {
+        i8_pass_generic(a, sa, sb, lds);
     }
 }
 
@@ -460,8 +656,8 @@ __global__ void __launch_bounds__(256) k_i8_finish(int m, int n, const int *__re
                                                    const unsigned long long *__restrict__ W)
 {
     if (info[INFO_PATH] != PATH_I8) return;
-    const int sa = info[INFO_SA], sb = info[INFO_SB];
-    if (!force_multi && sa <= I8_SMAX && sb <= I8_SMAX) return;  // the single pass wrote C itself
+    const int sa = info[INFO_SA], sb = info[INFO_SB], bs = info[INFO_BS];
+    if (!force_multi && sa <= bs && sb <= bs) return;  // the single pass wrote C itself
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long long)m * n) return;
     const int gi = (int)(idx / n), gj = (int)(idx % n);
@@ -478,7 +674,7 @@ __global__ void __launch_bounds__(256) k_i8_zero_w(long long words, const int *_
                                                    unsigned long long *__restrict__ W)
 {
     if (info[INFO_PATH] != PATH_I8) return;
-    if (!force_multi && info[INFO_SA] <= I8_SMAX && info[INFO_SB] <= I8_SMAX) return;
+    if (!force_multi && info[INFO_SA] <= info[INFO_BS] && info[INFO_SB] <= info[INFO_BS]) return;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < words; i += (long long)gridDim.x * 256) W[i] = 0ull;
 }
 
@@ -566,9 +762,8 @@ hipError_t exgemm_i8(Ctx &c, char transa, char transb, int m, int n, int k, doub
         const int kc0 = kp * (I8_KPASS / I8_T), kc1 = min(KC, kc0 + I8_KPASS / I8_T);
         for (int pa_ = 0; pa_ < dblocks; ++pa_)
             for (int pb_ = 0; pb_ < dblocks; ++pb_)
-                hipLaunchKernelGGL(k_gemm_i8, dim3(gy * gx), dim3(256), 0, st, m, n, KC, kc0, kc1, pa_ * I8_SMAX,
-                                   pb_ * I8_SMAX, PA, PB, info, EA, EB, beta, cmat, (long long)ldc, round_mode,
-                                   force_multi ? 0 : 1, W);
+                hipLaunchKernelGGL(k_gemm_i8, dim3(gy * gx), dim3(256), 0, st, m, n, KC, kc0, kc1, pa_, pb_, PA, PB, info,
+                                   EA, EB, beta, cmat, (long long)ldc, round_mode, force_multi ? 0 : 1, W);
     }
     if (maybe_multi)
         hipLaunchKernelGGL(k_i8_finish, dim3((unsigned)(((long long)m * n + 255) / 256)), dim3(256), 0, st, m, n, info,

@@ -15,6 +15,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <thread>
+#include <vector>
 
 namespace exb {
 
@@ -113,7 +116,8 @@ Ctx &ctx(int device, int layer)
         c.gflags = c.gflags_all;
         c.slot = 0;
         EXB_CHECK(hipMalloc(&c.d_record, sizeof(long long) * OUT_WORDS));
-        EXB_CHECK(hipHostMalloc(&c.h_record, sizeof(long long) * OUT_WORDS));
+        // portable: the record of one device's part is copied to the first device when a host call spans several
+        EXB_CHECK(hipHostMalloc(&c.h_record, sizeof(long long) * OUT_WORDS, hipHostMallocPortable));
         EXB_CHECK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
         EXB_CHECK(hipDeviceSynchronize());
         EXB_CHECK(hipSetDevice(prev));
@@ -616,31 +620,167 @@ static void check_fpe(int fpe)
     }
 }
 
+// ---- ExSUM / ExDOT of host vectors ---------------------------------------------------------------------------
+// The reference's GPU backend copies the whole vector to ONE device per call (gpu:ExSUM.cpp:126), its CPU backend
+// scatters slices from rank 0 to the other ranks (cpu:ExSUM.cpp:33-63).  Here one call spreads the vector over the
+// GPUs of the node: every "virtual device" (a GPU, with a private host-layer context) gets a contiguous part, streams
+// it through its own PCIe link in 64 MiB chunks (copy, accumulate kernel, copy, ...: bounded staging memory, the
+// kernels hide behind the copies) and normalises its sum; the parts' 576-byte digit sets are then added and rounded
+// once on the first device -- so the bits do not depend on how many GPUs took part.
+static std::mutex g_host_mu;           // host-pointer calls are serialised process-wide (the reference's are not re-entrant at all)
+static std::vector<int> g_host_devs;   // set by exblas_set_host_devices / EXBLAS_HOST_DEVICES; empty = default policy
+static bool g_host_devs_env_read = false;
+constexpr long long HOST_CHUNK_ELEMS = 8ll << 20;          // 64 MiB of doubles per copy
+constexpr long long HOST_SPLIT_MIN_BYTES = 256ll << 20;    // smaller inputs stay on the current device
+
+static std::vector<int> host_devices(long long bytes)
+{
+    if (!g_host_devs_env_read) {
+        g_host_devs_env_read = true;
+        const char *e = getenv("EXBLAS_HOST_DEVICES");  // "all", "current", or a list such as "0,1,2" / "0,0"
+        if (e && *e && g_host_devs.empty()) {
+            int ndev = exblas_hip_device_count();
+            if (!strcmp(e, "all")) {
+                for (int d = 0; d < ndev && d < MAX_LAYERS - 1; ++d) g_host_devs.push_back(d);
+            } else if (strcmp(e, "current")) {
+                for (const char *q = e; *q;) {
+                    char *end;
+                    long d = strtol(q, &end, 10);
+                    if (end == q) break;
+                    if (d >= 0 && d < ndev && (int)g_host_devs.size() < MAX_LAYERS - 1) g_host_devs.push_back((int)d);
+                    q = *end ? end + 1 : end;
+                }
+            } else {
+                g_host_devs.push_back(-1);  // current device only
+            }
+        }
+    }
+    std::vector<int> devs = g_host_devs;
+    if (devs.empty()) {
+        // default: one big call uses every GPU this process can see (8 PCIe links instead of 1); small ones do not
+        // pay for waking the other devices
+        const int ndev = exblas_hip_device_count();
+        if (bytes >= HOST_SPLIT_MIN_BYTES && ndev > 1)
+            for (int d = 0; d < ndev && d < MAX_LAYERS - 1; ++d) devs.push_back(d);
+        else
+            devs.push_back(-1);
+    }
+    const int cur = current_device();
+    for (int &d : devs)
+        if (d < 0) d = cur;
+    return devs;
+}
+
+struct HostPart {
+    int dev = 0, layer = 1;
+    long long i0 = 0, i1 = 0;
+    int rc = 0;
+    const char *what = "";
+};
+
+// one part of the vector(s) on one virtual device; leaves the part's record in the context's pinned h_record
+static void host_reduce_part(HostPart &p, const double *a, long long inca, const double *b, long long incb, int fpe,
+                             int early_exit)
+{
+    hipError_t e = hipSetDevice(p.dev);
+    if (e != hipSuccess) { p.rc = (int)e; p.what = "hipSetDevice"; return; }
+    Ctx &c = ctx(p.dev, p.layer);
+    for (long long i = p.i0; i < p.i1 && !p.rc; i += HOST_CHUNK_ELEMS) {
+        const long long cnt = std::min(HOST_CHUNK_ELEMS, p.i1 - i);
+        const size_t spa = ((size_t)(cnt - 1) * (size_t)inca + 1) * sizeof(double);
+        double *da, *db = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(c.mu);
+            da = (double *)stage_buf(c, 0, spa);
+            if (b) db = (double *)stage_buf(c, 1, ((size_t)(cnt - 1) * (size_t)incb + 1) * sizeof(double));
+        }
+        // element count semantics of the GPU backend: a[offset + i*inca] (ExSUM.Superacc.cl:249-250); the touched
+        // span of the chunk is copied like gpu:ExSUM.cpp:126 copies the whole vector
+        e = hipMemcpyAsync(da, a + i * inca, spa, hipMemcpyHostToDevice, c.stream);
+        if (e == hipSuccess && b)
+            e = hipMemcpyAsync(db, b + i * incb, ((size_t)(cnt - 1) * (size_t)incb + 1) * sizeof(double),
+                               hipMemcpyHostToDevice, c.stream);
+        if (e != hipSuccess) { p.rc = (int)e; p.what = "hipMemcpyAsync"; return; }
+        p.rc = b ? exdot_accumulate_on(c, da, inca, db, incb, cnt, fpe, early_exit, c.stream)
+                 : exsum_accumulate_on(c, da, cnt, inca, fpe, early_exit, c.stream);
+        p.what = "accumulate";
+    }
+    if (p.rc) return;
+    p.rc = finish_on(c, c.stream, (int64_t *)c.d_record);
+    p.what = "finish";
+    if (p.rc) return;
+    e = hipMemcpyAsync(c.h_record, c.d_record, sizeof(long long) * OUT_WORDS, hipMemcpyDeviceToHost, c.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c.stream);
+    if (e != hipSuccess) { p.rc = (int)e; p.what = "record copy"; }
+}
+
+static int host_reduce(long long n, const double *a, long long inca, const double *b, long long incb, int fpe,
+                       int early_exit, int64_t *out_words)
+{
+    std::lock_guard<std::mutex> host_lock(g_host_mu);
+    const int home = current_device();
+    if (n < 0) n = 0;
+    std::vector<int> devs = host_devices(n * (long long)sizeof(double) * (b ? 2 : 1));
+    const int nv = (int)std::min<long long>((long long)devs.size(), std::max<long long>(1, n / 2));
+    std::vector<HostPart> parts(nv);
+    for (int v = 0; v < nv; ++v) {
+        parts[v].dev = devs[v];
+        parts[v].layer = 1 + v;
+        parts[v].i0 = (n * v) / nv;
+        parts[v].i1 = (n * (v + 1)) / nv;
+    }
+    if (nv == 1) {
+        host_reduce_part(parts[0], a, inca, b, incb, fpe, early_exit);
+    } else {
+        std::vector<std::thread> th;
+        for (int v = 0; v < nv; ++v)
+            th.emplace_back([&, v] { host_reduce_part(parts[v], a, inca, b, incb, fpe, early_exit); });
+        for (auto &t : th) t.join();
+    }
+    EXB_CHECK(hipSetDevice(home));
+    for (auto &p : parts)
+        if (p.rc) die(p.what, (hipError_t)p.rc, __FILE__, __LINE__);
+    Ctx &c0 = ctx(parts[0].dev, parts[0].layer);
+    if (nv > 1) {
+        // add the parts' digit sets and round once, on the first device (exblas_finalize_dev's job in the *_dev layer)
+        EXB_CHECK(hipSetDevice(c0.device));
+        long long *d_sets;
+        {
+            std::lock_guard<std::mutex> lk(c0.mu);
+            d_sets = (long long *)stage_buf(c0, 2, sizeof(long long) * SET_WORDS * nv);
+        }
+        for (int v = 0; v < nv; ++v) {
+            Ctx &cv = ctx(parts[v].dev, parts[v].layer);
+            EXB_CHECK(hipMemcpyAsync(d_sets + (size_t)v * SET_WORDS, cv.h_record + OUT_DIGITS,
+                                     sizeof(long long) * SET_WORDS, hipMemcpyHostToDevice, c0.stream));
+        }
+        EXB_CHECK(finalize_sets(d_sets, nv, 0u, c0.stream, c0.d_record));
+        EXB_CHECK(hipMemcpyAsync(c0.h_record, c0.d_record, sizeof(long long) * OUT_WORDS, hipMemcpyDeviceToHost,
+                                 c0.stream));
+        EXB_CHECK(hipStreamSynchronize(c0.stream));
+        EXB_CHECK(hipSetDevice(home));
+    }
+    memcpy(out_words, c0.h_record, sizeof(long long) * OUT_WORDS);
+    return nv;
+}
+
+int exblas_set_host_devices(int count, const int *devices)
+{
+    std::lock_guard<std::mutex> host_lock(g_host_mu);
+    const int ndev = exblas_hip_device_count();
+    if (count < 0 || count > MAX_LAYERS - 1) return (int)hipErrorInvalidValue;
+    for (int i = 0; i < count; ++i)
+        if (devices[i] < 0 || devices[i] >= ndev) return (int)hipErrorInvalidDevice;
+    g_host_devs.assign(devices, devices + count);  // count == 0: back to the default policy
+    g_host_devs_env_read = true;
+    return 0;
+}
+
 int exblas_exsum_record(int Ng, const double *ag, int inca, int offset, int fpe, int early_exit,
                         int64_t *out_words)
 {
     check_fpe(fpe);
-    Ctx &c = ctx(-1, 1);
-    std::lock_guard<std::mutex> api_lock(c.api_mu);
-    const double *d_a = nullptr;
-    {
-        std::lock_guard<std::mutex> lk(c.mu);
-        if (Ng > 0) {
-            // element count semantics of the GPU backend: a[offset + i*inca], i < Ng
-            // (ExSUM.Superacc.cl:249-250); the whole touched span is copied like gpu:ExSUM.cpp:126
-            size_t span = (size_t)(Ng - 1) * (size_t)(inca > 0 ? inca : 1) + 1;
-            double *buf = (double *)stage_buf(c, 0, span * sizeof(double));
-            EXB_CHECK(hipMemcpyAsync(buf, ag + offset, span * sizeof(double), hipMemcpyHostToDevice, c.stream));
-            d_a = buf;
-        }
-    }
-    int rc = exsum_accumulate_on(c, d_a, Ng > 0 ? Ng : 0, inca > 0 ? inca : 1, fpe, early_exit, c.stream);
-    if (!rc) rc = finish_on(c, c.stream, (int64_t *)c.d_record);
-    if (rc) die("exblas_exsum", (hipError_t)rc, __FILE__, __LINE__);
-    EXB_CHECK(hipMemcpyAsync(c.h_record, c.d_record, sizeof(long long) * OUT_WORDS, hipMemcpyDeviceToHost,
-                             c.stream));
-    EXB_CHECK(hipStreamSynchronize(c.stream));
-    memcpy(out_words, c.h_record, sizeof(long long) * OUT_WORDS);
+    host_reduce(Ng > 0 ? Ng : 0, ag + offset, inca > 0 ? inca : 1, nullptr, 1, fpe, early_exit, out_words);
     return 0;
 }
 
@@ -648,30 +788,8 @@ int exblas_exdot_record(int Ng, const double *ag, int inca, int offseta, const d
                         int fpe, int early_exit, int64_t *out_words)
 {
     check_fpe(fpe);
-    Ctx &c = ctx(-1, 1);
-    std::lock_guard<std::mutex> api_lock(c.api_mu);
-    const double *d_a = nullptr, *d_b = nullptr;
-    {
-        std::lock_guard<std::mutex> lk(c.mu);
-        if (Ng > 0) {
-            size_t spa = (size_t)(Ng - 1) * (size_t)(inca > 0 ? inca : 1) + 1;
-            size_t spb = (size_t)(Ng - 1) * (size_t)(incb > 0 ? incb : 1) + 1;
-            double *ba = (double *)stage_buf(c, 0, spa * sizeof(double));
-            double *bb = (double *)stage_buf(c, 1, spb * sizeof(double));
-            EXB_CHECK(hipMemcpyAsync(ba, ag + offseta, spa * sizeof(double), hipMemcpyHostToDevice, c.stream));
-            EXB_CHECK(hipMemcpyAsync(bb, bg + offsetb, spb * sizeof(double), hipMemcpyHostToDevice, c.stream));
-            d_a = ba;
-            d_b = bb;
-        }
-    }
-    int rc = exdot_accumulate_on(c, d_a, inca > 0 ? inca : 1, d_b, incb > 0 ? incb : 1, Ng > 0 ? Ng : 0, fpe,
-                                 early_exit, c.stream);
-    if (!rc) rc = finish_on(c, c.stream, (int64_t *)c.d_record);
-    if (rc) die("exblas_exdot", (hipError_t)rc, __FILE__, __LINE__);
-    EXB_CHECK(hipMemcpyAsync(c.h_record, c.d_record, sizeof(long long) * OUT_WORDS, hipMemcpyDeviceToHost,
-                             c.stream));
-    EXB_CHECK(hipStreamSynchronize(c.stream));
-    memcpy(out_words, c.h_record, sizeof(long long) * OUT_WORDS);
+    host_reduce(Ng > 0 ? Ng : 0, ag + offseta, inca > 0 ? inca : 1, bg + offsetb, incb > 0 ? incb : 1, fpe, early_exit,
+                out_words);
     return 0;
 }
 
@@ -704,7 +822,7 @@ int exblas_exgemv(char transa, int m, int n, double alpha, const double *a, int 
     check_fpe(fpe);
     if (m <= 0 || n <= 0) return 0;
     Ctx &c = ctx(-1, 1);
-    std::lock_guard<std::mutex> api_lock(c.api_mu);
+    std::lock_guard<std::mutex> api_lock(g_host_mu);
     const bool trans = (transa == 'T' || transa == 't');
     const int rows = trans ? n : m, inner = trans ? m : n;
     double *d_a, *d_x, *d_y;
@@ -738,7 +856,7 @@ int exblas_extrsv(char uplo, char transa, char diag, int n, const double *a, int
     }
     if (n <= 0) return 0;
     Ctx &c = ctx(-1, 1);
-    std::lock_guard<std::mutex> api_lock(c.api_mu);
+    std::lock_guard<std::mutex> api_lock(g_host_mu);
     double *d_a, *d_x;
     const size_t abytes = ((size_t)lda * (size_t)(n - 1) + (size_t)n) * sizeof(double);  // n columns of lda
     const size_t xspan = (size_t)(n - 1) * (size_t)incx + 1;
@@ -762,7 +880,7 @@ int exblas_exgemm(char transa, char transb, int m, int n, int k, double alpha, c
     check_fpe(fpe);
     if (m <= 0 || n <= 0) return 0;
     Ctx &c = ctx(-1, 1);
-    std::lock_guard<std::mutex> api_lock(c.api_mu);
+    std::lock_guard<std::mutex> api_lock(g_host_mu);
     const bool ta = (transa == 'T' || transa == 't'), tb = (transb == 'T' || transb == 't');
     // row-major storage (ExGEMM.Superacc.cl:254-255): A is m x k (k x m when transposed), etc.
     size_t abytes = (size_t)(ta ? k : m) * (size_t)lda * sizeof(double);

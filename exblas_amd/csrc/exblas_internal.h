@@ -48,7 +48,6 @@ struct Ctx {
     std::vector<void *> retired;
     int layer = 0;      // 0: the *_dev layer's context, >= 1: a private context of the host-pointer layer
     std::mutex mu;      // guards launches that touch the context workspace
-    std::mutex api_mu;  // held by a host-pointer call for its whole duration (staging buffers, record, stream)
 };
 
 // layer 0: context of the device-pointer (*_dev) entry points; layers 1..: the host-pointer API's own contexts (own

@@ -9,7 +9,7 @@
 namespace exb {
 
 // info words written by the scan kernels
-enum { INFO_NEED_A = 0, INFO_NEED_B = 1, INFO_FLAGS = 2, INFO_EMIN = 3, INFO_EMAX = 4, INFO_WORDS = 8 };
+enum { INFO_NEED_A = 0, INFO_NEED_B = 1, INFO_FLAGS = 2, INFO_EMIN = 3, INFO_EMAX = 4, INFO_WORDS = 16 };
 
 // ---------------------------------------------------------------------------------------------
 // scan: per vector (row of A' / column of B) the scale, and globally the number of bits to cover

@@ -234,6 +234,13 @@ int exblas_exgemm_sharded_dev(exblas_comm_t *comm, char transa, char transb, int
                               double *d_c, int ldc, int fpe, int early_exit, void *stream);
 
 /* ---- (1) host-pointer layer (reference semantics; copies H2D per call like gpu:ExSUM.cpp:126) -- */
+/* exsum / exdot of host vectors spread one call over several GPUs of the node (each streams its contiguous part in
+ * 64 MiB chunks through its own PCIe link; the 576-byte digit sets of the parts are added and rounded once): the
+ * reference's rank-0 scatter (cpu:ExSUM.cpp:33-63) inside one process.  Default: every visible device for inputs of
+ * 256 MiB or more, the current device otherwise; `EXBLAS_HOST_DEVICES=all|current|0,1,...` or this call override it
+ * (count == 0 restores the default; a device may be listed twice -- two independent parts on one GPU).  The result
+ * does not depend on the choice.  exgemv / exgemm / extrsv always use the current device. */
+int exblas_set_host_devices(int count, const int *devices);
 double exblas_exsum(int Ng, const double *ag, int inca, int offset, int fpe, int early_exit);
 double exblas_exdot(int Ng, const double *ag, int inca, int offseta, const double *bg, int incb,
                     int offsetb, int fpe, int early_exit);

@@ -335,3 +335,39 @@ def test_expansion_sizes_above_8(ex, oracle):
         assert ex.exdot(a.size, a, 1, 0, b, 1, 0, fpe, False) == d
         assert ex.exsum(a.size, a, 1, 0, fpe, True) == 0.0
         assert ex.exdot(a.size, a, 1, 0, b, 1, 0, fpe, True) == 0.0
+
+
+def test_host_api_spreads_over_virtual_devices(ex, oracle):
+    """The host-pointer exsum / exdot split one call over several "devices" (here: the one GPU listed several times,
+    each listing an independent part with its own context, stream and accumulators), stream every part in 64 MiB
+    chunks and add the parts' digit sets on the first device: records identical to the single-device *_dev path, for
+    contiguous, strided and offset inputs, whatever the device list."""
+    import ctypes as C
+    import torch
+    lib = ex.load_library()
+    n = (20 << 20) + 3                                     # > 2 chunks of 8M elements per part even when split in two
+    a = oracle.gen("ill_cond", n, 21, 1e32)
+    b = oracle.gen("lognormal", n, 22, 0.0, 2.0)
+    da, db = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    want_s = ex.read_record(ex.exsum_dev(da, 8, True))
+    want_d = ex.read_record(ex.exdot_dev(da, db, 8, True))
+    ns = 6_000_001
+    want_ss = ex.read_record(ex.exsum_dev(da[5:], 8, True, inca=3, n=ns))
+    want_ds = ex.read_record(ex.exdot_dev(da[5:], db[2:], 8, True, incx=3, incy=2, n=ns))
+    try:
+        for devs in ([0], [0, 0], [0, 0, 0], [0] * 8):
+            arr = (C.c_int * len(devs))(*devs)
+            assert lib.exblas_set_host_devices(len(devs), arr) == 0
+            for got, want in ((ex.exsum_record(n, a, 1, 0, 8, True), want_s),
+                              (ex.exdot_record(n, a, 1, 0, b, 1, 0, 8, True), want_d),
+                              (ex.exsum_record(ns, a, 3, 5, 8, True), want_ss),
+                              (ex.exdot_record(ns, a, 3, 5, b, 2, 2, 8, True), want_ds)):
+                assert got.exact == want.exact and got.refmode == want.refmode and (got.canon == want.canon).all(), devs
+            assert ex.exsum(1, a, 1, 0, 8, True) == a[0]                 # fewer elements than parts
+            assert ex.exsum(3, a, 1, 0, 0) == oracle.exsum(a[:3], 0)
+            bad = a[:1000].copy()
+            bad[17] = np.inf
+            assert ex.exsum(1000, bad, 1, 0, 8, True) == np.inf          # the non-finite indicators travel with the digit sets
+        assert lib.exblas_set_host_devices(1, (C.c_int * 1)(7)) != 0     # no such device on this box
+    finally:
+        lib.exblas_set_host_devices(0, None)

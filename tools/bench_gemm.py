@@ -12,11 +12,12 @@ paths = [int(v) for v in (sys.argv[3] if len(sys.argv) > 3 else "0,3").split(","
 kind = sys.argv[4] if len(sys.argv) > 4 else "fpuniform"
 p0 = float(sys.argv[5]) if len(sys.argv) > 5 else 10.0
 p1 = float(sys.argv[6]) if len(sys.argv) > 6 else 0.0
+rounds = int(sys.argv[7]) if len(sys.argv) > 7 else 3
 lib = ex.load_library()
 A = ex.gen_dev(kind, rows * n, 4, p0, p1)
 B = ex.gen_dev(kind, n * n, 5, p0, p1)
 res = {}
-for rnd in range(3):
+for rnd in range(rounds):
     for path in paths:
         lib.exblas_set_gemm_path(path)
         Cm = torch.zeros(rows * n, dtype=torch.float64, device="cuda")
