@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(BLOCK) k_exsum(const double *__restrict__ a, l
     constexpr long long TILE = (long long)BLOCK * U;
     const long long ntiles = nv / TILE;
     LdsSink<COPIES> sinkm{col, flags};
-    int bypass = 0;
+    Bypass bypass;
 
     if constexpr (!PF) {
         for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
@@ -207,7 +207,7 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_exdot(const double *__restrict__
     // vector path only when both streams are 16-byte aligned (host guarantees or falls to strided)
     const d2_t *va = (const d2_t *)a, *vb = (const d2_t *)b;
     const long long nv = n >> 1;
-    int bypass = 0;
+    Bypass bypass;
     constexpr long long TILE = (long long)BLOCK * U;
     const long long ntiles = nv / TILE;
     if constexpr (!PF) {
@@ -450,7 +450,11 @@ static inline int grid_for(const Ctx &c, long long work_items, long long per_blo
 template <int N, bool EE, int COPIES, int U, bool NT, bool PF, int ZM = 0>
 static void run_exsum(Ctx &c, const double *a, long long n, hipStream_t st)
 {
-    int grid = grid_for(c, n, (long long)BLOCK * 2 * U, N == 0 ? c.bpc_sa : c.bpc_sum);
+    // resident blocks per CU: the HBM-bound kernels want few fat blocks; the variants that run the full N-level cascade
+    // on every element (no early exit, N >= 5: 30-48 dependent fp64 adds per element) are VALU-latency-bound and want
+    // more waves per SIMD to hide it
+    const int bpc = N == 0 ? c.bpc_sa : ((!EE && N >= 5) ? c.bpc_heavy : c.bpc_sum);
+    int grid = grid_for(c, n, (long long)BLOCK * 2 * U, bpc);
     hipLaunchKernelGGL((k_exsum<N, EE, COPIES, U, NT, PF, ZM>), dim3(grid), dim3(BLOCK), 0, st, a, n, c.gacc, c.gflags,
                        c.ngroups, c.variant == 9 ? 1 : 0);
 }

@@ -214,7 +214,7 @@ __global__ void __launch_bounds__(GV_BLOCK) k_gemvT(int m, double alpha, const d
 
     const bool vec = incx == 1 && ((((uintptr_t)col) | ((uintptr_t)x)) & 15u) == 0;
     long long done = 0;
-    int bypass = 0;
+    Bypass bypass;
     if (vec) {
         const d2_t *va = (const d2_t *)col, *vx = (const d2_t *)x;
         const long long nv = m >> 1, tile = (long long)GV_BLOCK * U, ntiles = nv / tile;

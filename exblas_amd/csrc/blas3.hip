@@ -42,7 +42,7 @@ __global__ void __launch_bounds__(GM_THREADS) k_gemm(int ta, int tb, int m, int 
 #pragma unroll
     for (int q = 0; q < (N > 0 ? N : 1); ++q) f[q] = 0.0;
 
-    int bypass = 0;
+    Bypass bypass;
     for (int l0 = 0; l0 < k; l0 += GM_KB) {
         __syncthreads();
         // A tile: rows i0..i0+15, depth l0..l0+31 ; B tile: depth x cols j0..j0+15

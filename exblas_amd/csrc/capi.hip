@@ -98,6 +98,7 @@ Ctx &ctx(int device, int layer)
         c.bpc_sum = env_int("EXBLAS_BPC_SUM", 2);
         c.bpc_dot = env_int("EXBLAS_BPC_DOT", 32);
         c.bpc_sa = env_int("EXBLAS_BPC_SA", 3);
+        c.bpc_heavy = env_int("EXBLAS_BPC_HEAVY", 4);
         c.ngroups = env_int("EXBLAS_NGROUPS", 32);
         if (c.ngroups < 1) c.ngroups = 1;
         c.variant = env_int("EXBLAS_VARIANT", 0);
@@ -105,6 +106,7 @@ Ctx &ctx(int device, int layer)
         if (layer > 0 && g_ctx[0][device].device >= 0) {  // knobs set through the API so far apply to every layer
             const Ctx &z = g_ctx[0][device];
             c.blocks_per_cu = z.blocks_per_cu; c.bpc_sum = z.bpc_sum; c.bpc_dot = z.bpc_dot; c.bpc_sa = z.bpc_sa;
+            c.bpc_heavy = z.bpc_heavy;
             c.ngroups = z.ngroups; c.variant = z.variant; c.gemm_path = z.gemm_path;
             c.gemm_max_slices = z.gemm_max_slices;
         }
@@ -328,7 +330,7 @@ int exblas_set_tuning(int blocks_per_cu, int ngroups, int variant)
     ctx(-1);
     for_each_layer(current_device(), [&](Ctx &c) {
         std::lock_guard<std::mutex> lk(c.mu);
-        if (blocks_per_cu > 0) c.blocks_per_cu = c.bpc_sum = c.bpc_dot = c.bpc_sa = blocks_per_cu;
+        if (blocks_per_cu > 0) c.blocks_per_cu = c.bpc_sum = c.bpc_dot = c.bpc_sa = c.bpc_heavy = blocks_per_cu;
         if (ngroups > 0 && ngroups != c.ngroups) {
             EXB_CHECK(hipDeviceSynchronize());
             EXB_CHECK(hipFree(c.gacc_all));

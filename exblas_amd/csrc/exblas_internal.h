@@ -18,6 +18,7 @@ struct Ctx {
     // blocks (2 per CU: 7.15 TB/s vs 6.46 at 8), the two-stream ExDOT kernel with many (16-32 per CU).
     int bpc_sum = 2, bpc_dot = 32;
     int bpc_sa = 3;          // superaccumulator-only ExSUM (LDS-atomic bound; 3/CU: 6.65 TB/s, 2/CU: 6.0)
+    int bpc_heavy = 4;       // ExSUM variants without early exit, N >= 5 (VALU-latency-bound)
     int ngroups = 32;        // EXBLAS_NGROUPS: global group accumulators the blocks add into
     int variant = 0;         // tuning variant of the production kernels (exblas_set_tuning)
     // which ExGEMM implementation the last call used.  The int8 path decides on the device: gemm_info_dev then points

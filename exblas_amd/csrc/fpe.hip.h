@@ -148,25 +148,37 @@ __device__ __forceinline__ bool fpe_absorb_sink(double (&a)[N > 0 ? N : 1], doub
     }
 }
 
-// Adaptive front-end of the early-exit variants.  When a tile had to spill (its residues outlived all N levels:
-// the data's exponent range is wider than the expansion can hold), the next BYPASS_TILES tiles skip the expansion
-// and go straight to the integer accumulator -- which on gfx950 streams at ~6 TB/s on its own -- before the
-// expansion is tried again.  Wide-range inputs then cost about what the superaccumulator-only variant costs instead
-// of N TwoSum levels PLUS the spill per element; well-conditioned inputs never take the branch.  Exact either way.
-constexpr int BYPASS_TILES = 63;
+// Adaptive front-end.  When a tile had to spill (its residues outlived all N levels: the data's exponent range is wider
+// than the expansion can hold), the following tiles skip the expansion and go straight to the integer accumulator --
+// which on gfx950 streams at ~6 TB/s on its own -- before the expansion is tried again; every spill in a row doubles
+// the length of the bypass (BYPASS_MIN .. BYPASS_MAX tiles), a tile the expansion absorbs resets it.  Wide-range inputs
+// then cost what the superaccumulator-only variant costs instead of N TwoSum levels PLUS the spill per element;
+// well-conditioned inputs never take the branch.  This is a property of the DATA, not of the variant: the N-level
+// cascade of a variant without early exit is run, unconditionally and in full, on every tile the expansion is tried on
+// (the reference's FPE kernels flush the whole expansion per surviving element instead, ExSUM.FPE.cl:262-292).
+// The sum is exact either way, and so are the limbs the parity tests compare.
+constexpr int BYPASS_MIN = 63, BYPASS_MAX = 4095;
+
+struct Bypass {
+    int left = 0;    // tiles still to go straight to the integer accumulator (wave-uniform)
+    int span = BYPASS_MIN;
+};
 
 template <int N, bool EE, int CNT, class Sink, int ZM = 0>
-__device__ __forceinline__ void fpe_absorb_adaptive(double (&a)[N > 0 ? N : 1], double (&x)[CNT], Sink &sink, int &bypass)
+__device__ __forceinline__ void fpe_absorb_adaptive(double (&a)[N > 0 ? N : 1], double (&x)[CNT], Sink &sink, Bypass &bp)
 {
-    if constexpr (N == 0 || !EE) {
+    if constexpr (N == 0) {
         fpe_absorb_sink<N, EE, CNT, Sink, ZM>(a, x, 0, sink);
     } else {
-        if (bypass > 0) {  // wave-uniform
-            --bypass;
+        if (bp.left > 0) {  // wave-uniform
+            --bp.left;
 #pragma unroll
             for (int j = 0; j < CNT; ++j) sink.add(x[j]);
         } else if (fpe_absorb_sink<N, EE, CNT, Sink, ZM>(a, x, 0, sink)) {
-            bypass = BYPASS_TILES;
+            bp.left = bp.span;
+            bp.span = min(2 * bp.span + 1, BYPASS_MAX);
+        } else {
+            bp.span = BYPASS_MIN;
         }
     }
 }
@@ -196,20 +208,23 @@ __device__ __forceinline__ bool fpe_absorb_prod(double (&a)[N > 0 ? N : 1], doub
 // adaptive form for products (see fpe_absorb_adaptive)
 template <int N, bool EE, int CNT, class Sink>
 __device__ __forceinline__ void fpe_absorb_prod_adaptive(double (&a)[N > 0 ? N : 1], double (&p)[CNT],
-                                                         double (&e)[CNT], Sink &sink, int &bypass)
+                                                         double (&e)[CNT], Sink &sink, Bypass &bp)
 {
-    if constexpr (N == 0 || !EE) {
+    if constexpr (N == 0) {
         fpe_absorb_prod<N, EE, CNT>(a, p, e, sink);
     } else {
-        if (bypass > 0) {
-            --bypass;
+        if (bp.left > 0) {
+            --bp.left;
 #pragma unroll
             for (int j = 0; j < CNT; ++j) {
                 sink.add(p[j]);
                 if (e[j] != 0.0 && expo_field(p[j]) != 0x7ffu) sink.add(e[j]);
             }
         } else if (fpe_absorb_prod<N, EE, CNT>(a, p, e, sink)) {
-            bypass = BYPASS_TILES;
+            bp.left = bp.span;
+            bp.span = min(2 * bp.span + 1, BYPASS_MAX);
+        } else {
+            bp.span = BYPASS_MIN;
         }
     }
 }

@@ -185,7 +185,7 @@ __global__ void __launch_bounds__(TB *TW) k_trsv(int n, const double *__restrict
 #pragma unroll
     for (int i = 0; i < (N > 0 ? N : 1); ++i) f[i] = 0.0;
     RowSink sink{acc + lane * TPITCH, &rflags[lane], &s_touched};
-    int bypass = 0;
+    Bypass bypass;
 
     for (int C = 0; C < R; ++C) {
         const int c0 = C * TB + w * TCW;
