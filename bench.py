@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--no-early-exit", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary line items (ExDOT, BLAS2/3, host API)")
+    ap.add_argument("--no-host-api", action="store_true",
+                    help="skip the host-pointer exsum() line item (its 64 MiB chunk launches of k_exsum would dilute the "
+                         "per-kernel averages of a rocprofv3 --stats run)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "hbm_traffic.json"),
                     help="per-launch HBM bytes from a separate rocprofv3 --pmc pass, if present")
     return ap.parse_args()
@@ -472,7 +475,7 @@ def main():
         if world > 1:
             gvm, gmm = reduce_max(blas23["exgemv"]["ms"], blas23["exgemm"]["ms"])
             blas23["exgemv"]["ms"], blas23["exgemm"]["ms"] = gvm, gmm
-        if world == 1:
+        if world == 1 and not args.no_host_api:
             host_api = bench_host_api(ex, torch, keep, args.fpe, ee)
     else:
         host0 = [t.cpu().numpy() for t in x0] if (world == 1 and not args.no_cpu_baseline) else None
