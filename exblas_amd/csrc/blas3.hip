@@ -105,32 +105,11 @@ static hipError_t gemm_variant(char transa, char transb, int m, int n, int k, do
     return hipGetLastError();
 }
 
-// variant selection: ExGEMM.cpp:78-99 (fpe < 3 superaccumulators only; early-exit buckets 4/6/8)
-hipError_t exgemm_dispatch(Ctx &c, char transa, char transb, int m, int n, int k, double alpha, const double *a,
-                           int lda, const double *b, int ldb, double beta, double *cmat, int ldc, int fpe,
-                           int early_exit, int round_mode, hipStream_t st)
+// one (fpe, early_exit) variant of the scalar kernel on a row block
+static hipError_t gemm_scalar(char transa, char transb, int m, int n, int k, double alpha, const double *a, int lda,
+                              const double *b, int ldb, double beta, double *cmat, int ldc, int fpe, int early_exit,
+                              int round_mode, hipStream_t st, const int *gate)
 {
-    if (m <= 0 || n <= 0) return hipSuccess;
-    c.last_gemm_slices = 0;
-    c.gemm_info_dev = nullptr;
-    if (early_exit && fpe > 8) return hipSuccess;  // the reference's silent no-op (ExGEMM.cpp:88-99), on every path
-    const int *gate = nullptr;
-    if (c.gemm_path == 3) {
-        // fp64 slices on MFMA-F64 (blas3_mfma.hip): exact-rounding mode, host-decided
-        if (round_mode == 0) {
-            hipError_t e = hipSuccess;
-            if (exgemm_try_mfma(c, transa, transb, m, n, k, alpha, a, lda, b, ldb, beta, cmat, ldc, st, &e)) return e;
-        }
-    } else if (c.gemm_path != 1) {
-        // int8 slices on the matrix cores (blas3_i8.hip) for every variant and both rounding modes: the result is the
-        // correctly rounded exact dot product whichever expansion size the caller names.  The scalar kernel below is
-        // enqueued behind it, predicated on the device-side decision.
-        bool launched = false;
-        hipError_t e = exgemm_i8(c, transa, transb, m, n, k, alpha, a, lda, b, ldb, beta, cmat, ldc, round_mode, st,
-                                 &launched, &gate);
-        if (e != hipSuccess) return e;
-        if (!launched) gate = nullptr;
-    }
 #define GM_ARGS transa, transb, m, n, k, alpha, a, lda, b, ldb, beta, cmat, ldc, round_mode, st, gate
     if (fpe < 3) return gemm_variant<0, false>(GM_ARGS);
     if (early_exit) {
@@ -147,6 +126,61 @@ hipError_t exgemm_dispatch(Ctx &c, char transa, char transb, int m, int n, int k
     default: return gemm_variant<8, false>(GM_ARGS);  // fpe >= 8: ExGEMM.FPE.cl with NBFPE = fpe (ExGEMM.cpp:96-97), same bits
     }
 #undef GM_ARGS
+}
+
+// variant selection: ExGEMM.cpp:78-99 (fpe < 3 superaccumulators only; early-exit buckets 4/6/8).
+// chunks != nullptr: the rows of C are produced chunk by chunk and chunks->hook runs after each (row-sharded GEMM).
+hipError_t exgemm_dispatch(Ctx &c, char transa, char transb, int m, int n, int k, double alpha, const double *a,
+                           int lda, const double *b, int ldb, double beta, double *cmat, int ldc, int fpe,
+                           int early_exit, int round_mode, hipStream_t st, const GemmChunks *chunks)
+{
+    if (m <= 0 || n <= 0) return hipSuccess;
+    c.last_gemm_slices = 0;
+    c.gemm_info_dev = nullptr;
+    if (early_exit && fpe > 8) return hipSuccess;  // the reference's silent no-op (ExGEMM.cpp:88-99), on every path
+    const bool ta = (transa == 'T' || transa == 't');
+    GemmChunks whole;
+    whole.n = 1;
+    whole.bound[0] = 0;
+    whole.bound[1] = m;
+    const GemmChunks &ch = chunks ? *chunks : whole;
+    // int8 slices on the matrix cores (blas3_i8.hip) for every variant and both rounding modes: the result is the
+    // correctly rounded exact dot product whichever expansion size the caller names.  The scalar kernel is enqueued
+    // behind it, predicated on the device-side decision.
+    I8Plan plan;
+    if (c.gemm_path != 1 && c.gemm_path != 3) {
+        hipError_t e = exgemm_i8_prepare(c, transa, transb, m, n, k, alpha, a, lda, b, ldb, beta, cmat, ldc, round_mode,
+                                         st, &plan);
+        if (e != hipSuccess) return e;
+    }
+    const int *gate = plan.ok ? plan.info + I8_INFO_PATH : nullptr;
+    for (int i = 0; i < ch.n; ++i) {
+        const int row0 = ch.bound[i], row1 = ch.bound[i + 1];
+        if (row1 > row0) {
+            const double *ar = ta ? a + row0 : a + (size_t)row0 * lda;
+            double *cr = cmat + (size_t)row0 * ldc;
+            bool done = false;
+            if (plan.ok) {
+                hipError_t e = exgemm_i8_rows(plan, row0, row1, st);
+                if (e != hipSuccess) return e;
+            } else if (c.gemm_path == 3 && round_mode == 0) {
+                // fp64 slices on MFMA-F64 (blas3_mfma.hip): exact-rounding mode, host-decided
+                hipError_t e = hipSuccess;
+                done = exgemm_try_mfma(c, transa, transb, row1 - row0, n, k, alpha, ar, lda, b, ldb, beta, cr, ldc, st, &e);
+                if (done && e != hipSuccess) return e;
+            }
+            if (!done) {
+                hipError_t e = gemm_scalar(transa, transb, row1 - row0, n, k, alpha, ar, lda, b, ldb, beta, cr, ldc, fpe,
+                                           early_exit, round_mode, st, gate);
+                if (e != hipSuccess) return e;
+            }
+        }
+        if (ch.hook) {
+            const int rc = ch.hook(ch.user, i, st);
+            if (rc) return (hipError_t)rc;
+        }
+    }
+    return hipSuccess;
 }
 
 }  // namespace exb

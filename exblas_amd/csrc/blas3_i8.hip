@@ -50,6 +50,7 @@ constexpr int I8_NWG = 5;        // 64-bit words of the per-entry accumulator in
 constexpr int I8_ERANGE = 300;   // |exponent| bound of the operands: keeps every rounded result a normal double
 
 enum { INFO_SA = 5, INFO_SB = 6, INFO_PATH = 7, INFO_BS = 8, INFO_EXACT = 9 };   // extends the scan's info block
+static_assert(INFO_PATH == I8_INFO_PATH, "exblas_internal.h");
 enum { PATH_SCALAR = 0, PATH_I8 = 2 };
 
 template <int B, int E, class F>
@@ -351,6 +352,7 @@ __device__ __forceinline__ void tile_of_block(int bid, int nbid, int gy, int gx,
 // ---- pieces shared by the pass bodies ------------------------------------------------------------------------
 struct PassArgs {
     int m, n, KC, kc0, kc1, ta0, tb0;
+    int ty0, ty_cnt;     // this launch covers the tile rows [ty0, ty0 + ty_cnt) (row chunks of the sharded GEMM)
     const signed char *PA, *PB;
     const int *EA, *EB;
     double beta;
@@ -416,9 +418,10 @@ __device__ __forceinline__ void i8_pass_exact(const PassArgs &a, LdsBuf lds)
 {
     constexpr int G = 2 * B - 1;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int gy = (a.m + I8_T - 1) / I8_T, gx = (a.n + I8_T - 1) / I8_T;
+    const int gx = (a.n + I8_T - 1) / I8_T;
     int ty, tx;
-    tile_of_block(blockIdx.x, gridDim.x, gy, gx, &ty, &tx);
+    tile_of_block(blockIdx.x, gridDim.x, a.ty_cnt, gx, &ty, &tx);
+    ty += a.ty0;
     const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
     const signed char *pa = a.PA + ((size_t)ty * a.KC * a.sa_all + a.ta0) * I8_TILE + (size_t)tid * 16;
     const signed char *pb = a.PB + ((size_t)tx * a.KC * a.sb_all + a.tb0) * I8_TILE + (size_t)tid * 16;
@@ -545,9 +548,10 @@ __device__ __forceinline__ void i8_pass_generic(const PassArgs &a, int sa, int s
 {
     constexpr int G = 2 * I8_SMAX - 1;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int gy = (a.m + I8_T - 1) / I8_T, gx = (a.n + I8_T - 1) / I8_T;
+    const int gx = (a.n + I8_T - 1) / I8_T;
     int ty, tx;
-    tile_of_block(blockIdx.x, gridDim.x, gy, gx, &ty, &tx);
+    tile_of_block(blockIdx.x, gridDim.x, a.ty_cnt, gx, &ty, &tx);
+    ty += a.ty0;
     const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
     const signed char *pa = a.PA + ((size_t)ty * a.KC * a.sa_all + a.ta0) * I8_TILE + (size_t)tid * 16;
     const signed char *pb = a.PB + ((size_t)tx * a.KC * a.sb_all + a.tb0) * I8_TILE + (size_t)tid * 16;
@@ -615,7 +619,7 @@ __device__ __forceinline__ void i8_pass_generic(const PassArgs &a, int sa, int s
 // One pass: C block (64 x 64 per workgroup) += digits [ta0, ta0+bs) of A  x  digits [tb0, tb0+bs) of B over k chunks
 // [kc0, kc1), where (ta0, tb0) = (ia, ib) * bs and bs is the digit block size the device chose (k_i8_decide).
 // allow_single: with one pass in all this launch rounds and writes C itself; otherwise it adds into W.
-__global__ void __launch_bounds__(256, 1) k_gemm_i8(int m, int n, int KC, int kc0, int kc1, int ia, int ib,
+__global__ void __launch_bounds__(256, 1) k_gemm_i8(int m, int n, int ty0, int ty_cnt, int KC, int kc0, int kc1, int ia, int ib,
                                                     const signed char *__restrict__ PA,
                                                     const signed char *__restrict__ PB, const int *__restrict__ info,
                                                     const int *__restrict__ EA, const int *__restrict__ EB,
@@ -632,7 +636,7 @@ __global__ void __launch_bounds__(256, 1) k_gemm_i8(int m, int n, int KC, int kc
     a.tb0 = ib * bs;
     if (a.ta0 >= a.sa_all || a.tb0 >= a.sb_all) return;
     const int sa = min(bs, a.sa_all - a.ta0), sb = min(bs, a.sb_all - a.tb0);
-    a.m = m; a.n = n; a.KC = KC; a.kc0 = kc0; a.kc1 = kc1;
+    a.m = m; a.n = n; a.KC = KC; a.kc0 = kc0; a.kc1 = kc1; a.ty0 = ty0; a.ty_cnt = ty_cnt;
     a.PA = PA; a.PB = PB; a.EA = EA; a.EB = EB;
     a.beta = beta; a.c = c; a.ldc = ldc; a.round_mode = round_mode; a.W = W;
     a.single = allow_single && a.sa_all <= bs && a.sb_all <= bs;
@@ -650,7 +654,7 @@ __global__ void __launch_bounds__(256, 1) k_gemm_i8(int m, int n, int KC, int kc
 }
 
 // multi-pass epilogue: round the 320-bit accumulators
-__global__ void __launch_bounds__(256) k_i8_finish(int m, int n, const int *__restrict__ info,
+__global__ void __launch_bounds__(256) k_i8_finish(int row0, int row1, int n, const int *__restrict__ info,
                                                    const int *__restrict__ EA, const int *__restrict__ EB, double beta,
                                                    double *__restrict__ c, long long ldc, int round_mode, int force_multi,
                                                    const unsigned long long *__restrict__ W)
@@ -658,12 +662,13 @@ __global__ void __launch_bounds__(256) k_i8_finish(int m, int n, const int *__re
     if (info[INFO_PATH] != PATH_I8) return;
     const int sa = info[INFO_SA], sb = info[INFO_SB], bs = info[INFO_BS];
     if (!force_multi && sa <= bs && sb <= bs) return;  // the single pass wrote C itself
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long long)m * n) return;
-    const int gi = (int)(idx / n), gj = (int)(idx % n);
+    const long long loc = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (loc >= (long long)(row1 - row0) * n) return;
+    const int gi = row0 + (int)(loc / n), gj = (int)(loc % n);
+    const size_t idx = (size_t)gi * n + gj;
     unsigned long long w[I8_NWG];
 #pragma unroll
-    for (int i = 0; i < I8_NWG; ++i) w[i] = W[(size_t)idx * I8_NWG + i];
+    for (int i = 0; i < I8_NWG; ++i) w[i] = W[idx * I8_NWG + i];
     const int u0 = EA[gi] - 8 * sa + 2 + EB[gj] - 8 * sb + 2;
     const double s = round_mode ? wide_round_reference<I8_NWG>(w, u0) : wide_round_n<I8_NWG>(w, u0);
     double *cij = c + (long long)gi * ldc + gj;
@@ -681,15 +686,18 @@ __global__ void __launch_bounds__(256) k_i8_zero_w(long long words, const int *_
 // ---------------------------------------------------------------------------------------------
 // host side: a pure sequence of launches
 // ---------------------------------------------------------------------------------------------
-// Returns hipSuccess with *launched = true when the int8 path was enqueued (it may still decide, on the device, to
-// leave the work to the scalar kernel: the caller enqueues that one predicated on info[INFO_PATH]).
-// *launched = false: not attempted (k == 0, workspace unavailable) -> the caller runs the scalar kernel unconditionally.
-hipError_t exgemm_i8(Ctx &c, char transa, char transb, int m, int n, int k, double alpha, const double *a, int lda,
-                     const double *b, int ldb, double beta, double *cmat, int ldc, int round_mode, hipStream_t st,
-                     bool *launched, const int **gate)
+// exgemm_i8_prepare: scan, decide, slice, zero the accumulators -- everything that concerns the WHOLE operands.  On
+// return plan->ok says whether the int8 path was enqueued (it may still decide, on the device, to leave the work to
+// the scalar kernel: the caller enqueues that one predicated on plan->info[INFO_PATH]); !ok: not attempted (k == 0,
+// workspace unavailable) -> the caller runs the scalar kernel unconditionally.
+// exgemm_i8_rows: the contraction passes (and the rounding of multi-pass accumulators) for the rows [row0, row1) of
+// C, row0 a multiple of 64.  A row-sharded caller (comm.hip) runs it chunk by chunk and ships every finished chunk
+// while the next one is computed; the operands are scanned and sliced once for all chunks.
+hipError_t exgemm_i8_prepare(Ctx &c, char transa, char transb, int m, int n, int k, double alpha, const double *a, int lda,
+                             const double *b, int ldb, double beta, double *cmat, int ldc, int round_mode,
+                             hipStream_t st, I8Plan *plan)
 {
-    *launched = false;
-    *gate = nullptr;
+    plan->ok = false;
     if (k <= 0 || m <= 0 || n <= 0) return hipSuccess;
     const int ta = (transa == 'T' || transa == 't'), tb = (transb == 'T' || transb == 't');
     const int gy = (m + I8_T - 1) / I8_T, gx = (n + I8_T - 1) / I8_T, KC = (k + I8_T - 1) / I8_T;
@@ -750,27 +758,40 @@ hipError_t exgemm_i8(Ctx &c, char transa, char transb, int m, int n, int k, doub
     else
         hipLaunchKernelGGL((k_i8_slice_contig<I8_SCAP>), dim3(KC, gx), dim3(256), 0, st, b, (long long)ldb, n, k, 1.0,
                            EB, info, 1, PB);
-
-    // ---- contract: passes over (digit block of A, digit block of B, k block); the device skips what the data does
-    // not need.  With one k pass and <= 8 digits on both sides the (0, 0) pass rounds and writes C itself.
     const int force_multi = kpasses > 1 ? 1 : 0;
     if (maybe_multi)
         hipLaunchKernelGGL(k_i8_zero_w, dim3(c.num_cu * 8), dim3(256), 0, st, (long long)m * n * I8_NWG, info,
                            force_multi, W);
-    const int dblocks = (scap + I8_SMAX - 1) / I8_SMAX;
-    for (int kp = 0; kp < kpasses; ++kp) {
-        const int kc0 = kp * (I8_KPASS / I8_T), kc1 = min(KC, kc0 + I8_KPASS / I8_T);
-        for (int pa_ = 0; pa_ < dblocks; ++pa_)
-            for (int pb_ = 0; pb_ < dblocks; ++pb_)
-                hipLaunchKernelGGL(k_gemm_i8, dim3(gy * gx), dim3(256), 0, st, m, n, KC, kc0, kc1, pa_, pb_, PA, PB, info,
-                                   EA, EB, beta, cmat, (long long)ldc, round_mode, force_multi ? 0 : 1, W);
-    }
-    if (maybe_multi)
-        hipLaunchKernelGGL(k_i8_finish, dim3((unsigned)(((long long)m * n + 255) / 256)), dim3(256), 0, st, m, n, info,
-                           EA, EB, beta, cmat, (long long)ldc, round_mode, force_multi, W);
-    *launched = true;
-    *gate = info + INFO_PATH;
+    plan->ok = true;
+    plan->m = m; plan->n = n; plan->KC = KC; plan->kpasses = kpasses;
+    plan->dblocks = (scap + I8_SMAX - 1) / I8_SMAX;
+    plan->force_multi = force_multi; plan->maybe_multi = maybe_multi ? 1 : 0;
+    plan->info = info; plan->EA = EA; plan->EB = EB; plan->PA = PA; plan->PB = PB; plan->W = W;
+    plan->beta = beta; plan->c = cmat; plan->ldc = ldc; plan->round_mode = round_mode;
     c.gemm_info_dev = info;
+    return hipGetLastError();
+}
+
+// contraction passes over (digit block of A, digit block of B, k block) for the rows [row0, row1); the device skips
+// what the data does not need.  With one k pass and one digit block on both sides the (0, 0) pass rounds and writes C
+// itself; otherwise k_i8_finish rounds the 320-bit accumulators of these rows.
+hipError_t exgemm_i8_rows(const I8Plan &p, int row0, int row1, hipStream_t st)
+{
+    if (row1 <= row0) return hipSuccess;
+    const int gx = (p.n + I8_T - 1) / I8_T;
+    const int ty0 = row0 / I8_T, ty_cnt = (row1 - row0 + I8_T - 1) / I8_T;
+    for (int kp = 0; kp < p.kpasses; ++kp) {
+        const int kc0 = kp * (I8_KPASS / I8_T), kc1 = min(p.KC, kc0 + I8_KPASS / I8_T);
+        for (int pa_ = 0; pa_ < p.dblocks; ++pa_)
+            for (int pb_ = 0; pb_ < p.dblocks; ++pb_)
+                hipLaunchKernelGGL(k_gemm_i8, dim3(ty_cnt * gx), dim3(256), 0, st, p.m, p.n, ty0, ty_cnt, p.KC, kc0, kc1,
+                                   pa_, pb_, p.PA, p.PB, p.info, p.EA, p.EB, p.beta, p.c, (long long)p.ldc, p.round_mode,
+                                   p.force_multi ? 0 : 1, p.W);
+    }
+    if (p.maybe_multi)
+        hipLaunchKernelGGL(k_i8_finish, dim3((unsigned)(((long long)(row1 - row0) * p.n + 255) / 256)), dim3(256), 0, st,
+                           row0, row1, p.n, p.info, p.EA, p.EB, p.beta, p.c, (long long)p.ldc, p.round_mode,
+                           p.force_multi, p.W);
     return hipGetLastError();
 }
 

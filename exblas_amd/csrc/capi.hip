@@ -455,13 +455,13 @@ static int extrsv_on(Ctx &c, char uplo, char transa, char diag, int n, const dou
 
 static int exgemm_on(Ctx &c, char transa, char transb, int m, int n, int k, double alpha, const double *d_a, int lda,
                      const double *d_b, int ldb, double beta, double *d_c, int ldc, int fpe, int early_exit,
-                     hipStream_t st)
+                     hipStream_t st, const GemmChunks *chunks = nullptr)
 {
     if (fpe < 0) return (int)hipErrorInvalidValue;
     std::lock_guard<std::mutex> lk(c.mu);
     g_last_layer[c.device] = c.layer;
     return (int)exgemm_dispatch(c, transa, transb, m, n, k, alpha, d_a, lda, d_b, ldb, beta, d_c, ldc, fpe,
-                                early_exit, round_mode(), st);
+                                early_exit, round_mode(), st, chunks);
 }
 
 int exblas_exsum_accumulate_dev(const double *d_a, int64_t n, int64_t inca, int fpe, int early_exit, void *stream)
@@ -538,6 +538,16 @@ int exblas_exgemm_dev(char transa, char transb, int m, int n, int k, double alph
     return exgemm_on(ctx(-1), transa, transb, m, n, k, alpha, d_a, lda, d_b, ldb, beta, d_c, ldc, fpe, early_exit,
                      (hipStream_t)stream);
 }
+
+}  // extern "C"
+int exb::exgemm_chunked_dev(char transa, char transb, int m, int n, int k, double alpha, const double *d_a, int lda,
+                            const double *d_b, int ldb, double beta, double *d_c, int ldc, int fpe, int early_exit,
+                            hipStream_t st, const GemmChunks *chunks)
+{
+    return exgemm_on(ctx(-1), transa, transb, m, n, k, alpha, d_a, lda, d_b, ldb, beta, d_c, ldc, fpe, early_exit, st,
+                     chunks);
+}
+extern "C" {
 
 int exblas_reserve_workspace(size_t bytes)
 {

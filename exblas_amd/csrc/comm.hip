@@ -415,31 +415,40 @@ int exblas_exgemm_sharded_dev(exblas_comm_t *cm, char transa, char transb, int m
     const int R = cm->nranks;
     long long r0, r1;
     shard(m, cm->rank, R, &r0, &r1);
-    // The local rows are computed in NCH chunks; the all-gather of chunk c (one piece per rank) runs on a side stream
-    // while chunk c+1 is computed.  Chunk boundaries are the same function of (m, R) on every rank.
+    // The operands are scanned and sliced ONCE; the local rows of C are then produced in NCH chunks (boundaries at
+    // multiples of 64 local rows, the tile height of the int8 kernel), and the all-gather of chunk c -- one piece per
+    // rank -- runs on a side stream while chunk c+1 is computed.  Chunk boundaries are the same function of (m, R) on
+    // every rank, so each rank knows every other rank's pieces.
     const bool overlap = multi && cm->kind == 0;
-    const int NCH = overlap ? ((r1 - r0) >= 2048 ? 4 : ((r1 - r0) >= 512 ? 2 : 1)) : 1;
+    const long long maxloc = (m + R - 1) / R + 2;
+    const int NCH = overlap ? (maxloc >= 2048 ? 4 : (maxloc >= 512 ? 2 : 1)) : 1;
     if (overlap && (rc = comm_side(cm)) != 0) return rc;
     auto chunk_rows = [&](int r, int c, long long *lo, long long *hi) {
         long long a0, a1;
         shard(m, r, R, &a0, &a1);
         const long long len = a1 - a0;
-        *lo = a0 + (len * c) / NCH;
-        *hi = a0 + (len * (c + 1)) / NCH;
+        auto cut = [&](int i) -> long long {
+            if (i >= NCH) return len;
+            const long long v = ((len * i / NCH) + 63) / 64 * 64;
+            return v < len ? v : len;
+        };
+        *lo = a0 + cut(c);
+        *hi = a0 + cut(c + 1);
     };
-    for (int c = 0; c < NCH; ++c) {
-        long long lo, hi;
-        chunk_rows(cm->rank, c, &lo, &hi);
-        if (hi > lo) {
-            const double *ap = ta ? d_a_local + (lo - r0) : d_a_local + (size_t)(lo - r0) * lda;
-            rc = exblas_exgemm_dev(transa, transb, (int)(hi - lo), n, k, alpha, ap, lda, d_b, ldb, beta,
-                                   d_c + (size_t)lo * ldc, ldc, fpe, early_exit, stream);
-            if (rc) return rc;
-        }
-        if (!multi) continue;
-        hipStream_t cs = st;
-        if (overlap) {
-            hipError_t e = hipEventRecord(cm->ev_chunk, st);
+    struct Ship {
+        exblas_comm *cm;
+        int NCH, R, m, ldc;
+        bool multi, overlap;
+        double *d_c;
+        decltype(chunk_rows) *rows;
+    } ship{cm, NCH, R, m, ldc, multi, overlap, d_c, &chunk_rows};
+    auto hook = [](void *u, int c, hipStream_t stc) -> int {
+        Ship &s = *(Ship *)u;
+        exblas_comm *cm = s.cm;
+        if (!s.multi) return 0;
+        hipStream_t cs = stc;
+        if (s.overlap) {
+            hipError_t e = hipEventRecord(cm->ev_chunk, stc);
             if (e == hipSuccess) e = hipStreamWaitEvent(cm->side, cm->ev_chunk, 0);
             if (e != hipSuccess) return (int)e;
             cs = cm->side;
@@ -448,27 +457,44 @@ int exblas_exgemm_sharded_dev(exblas_comm_t *cm, char transa, char transb, int m
         // all-gather is a group of per-owner broadcasts
         if (cm->kind == 0) {
             RcclApi &a = rccl();
-            rc = nccl_rc(a.GroupStart(), "ncclGroupStart");
-            for (int r = 0; r < R && !rc; ++r) {
+            int rc = nccl_rc(a.GroupStart(), "ncclGroupStart");
+            for (int r = 0; r < s.R && !rc; ++r) {
                 long long pl, ph;
-                chunk_rows(r, c, &pl, &ph);
+                (*s.rows)(r, c, &pl, &ph);
                 if (ph <= pl) continue;
-                double *p = d_c + (size_t)pl * ldc;
-                rc = nccl_rc(a.Broadcast(p, p, (size_t)(ph - pl) * ldc * sizeof(double), ncclChar, r, cm->nccl, cs),
+                double *p = s.d_c + (size_t)pl * s.ldc;
+                rc = nccl_rc(a.Broadcast(p, p, (size_t)(ph - pl) * s.ldc * sizeof(double), ncclChar, r, cm->nccl, cs),
                              "ncclBroadcast(C rows)");
             }
             const int rc2 = nccl_rc(a.GroupEnd(), "ncclGroupEnd");
-            if (rc || rc2) return rc ? rc : rc2;
-        } else {
-            std::vector<int64_t> off(R + 1);  // NCH == 1 here: the pieces are the ranks' whole row blocks, adjacent
-            for (int r = 0; r < R; ++r) {
-                long long pl, ph;
-                chunk_rows(r, c, &pl, &ph);
-                off[r] = pl * (int64_t)ldc * (int64_t)sizeof(double);
-                off[r + 1] = ph * (int64_t)ldc * (int64_t)sizeof(double);
-            }
-            if ((rc = comm_allgatherv(cm, d_c, off.data(), cs)) != 0) return rc;
+            return rc ? rc : rc2;
         }
+        std::vector<int64_t> off(s.R + 1);  // NCH == 1 here: the pieces are the ranks' whole row blocks, adjacent
+        for (int r = 0; r < s.R; ++r) {
+            long long pl, ph;
+            (*s.rows)(r, c, &pl, &ph);
+            off[r] = pl * (int64_t)s.ldc * (int64_t)sizeof(double);
+            off[r + 1] = ph * (int64_t)s.ldc * (int64_t)sizeof(double);
+        }
+        return comm_allgatherv(cm, s.d_c, off.data(), cs);
+    };
+    GemmChunks ch;
+    ch.n = NCH;
+    for (int c = 0; c <= NCH; ++c) {
+        long long lo, hi;
+        chunk_rows(cm->rank, c < NCH ? c : NCH - 1, &lo, &hi);
+        ch.bound[c] = (int)((c < NCH ? lo : hi) - r0);
+    }
+    ch.hook = hook;
+    ch.user = &ship;
+    if (r1 > r0) {
+        rc = exgemm_chunked_dev(transa, transb, (int)(r1 - r0), n, k, alpha, d_a_local, lda, d_b, ldb, beta,
+                                d_c + (size_t)r0 * ldc, ldc, fpe, early_exit, st, &ch);
+        if (rc) return rc;
+    } else {
+        // a rank without rows still takes part in every chunk's collective
+        for (int c = 0; c < NCH; ++c)
+            if ((rc = hook(&ship, c, st)) != 0) return rc;
     }
     if (overlap) {
         hipError_t e = hipEventRecord(cm->ev_done, cm->side);

@@ -67,6 +67,8 @@ void *workspace(Ctx &c, size_t bytes, hipStream_t st, hipError_t *err);
         if (_e != hipSuccess) exb::die(#expr, _e, __FILE__, __LINE__); \
     } while (0)
 
+struct GemmChunks;
+
 // blas1.hip
 hipError_t exsum_dispatch(Ctx &c, const double *a, long long n, long long inca, int fpe, int early_exit,
                           hipStream_t st, bool *supported);
@@ -83,15 +85,41 @@ hipError_t exgemv_dispatch(Ctx &c, char transa, int m, int n, double alpha, cons
                            int round_mode, hipStream_t st);
 hipError_t exgemm_dispatch(Ctx &c, char transa, char transb, int m, int n, int k, double alpha, const double *a,
                            int lda, const double *b, int ldb, double beta, double *cmat, int ldc, int fpe,
-                           int early_exit, int round_mode, hipStream_t st);
+                           int early_exit, int round_mode, hipStream_t st, const GemmChunks *chunks = nullptr);
 
 // trsv.hip
 hipError_t extrsv_dispatch(Ctx &c, char uplo, char transa, char diag, int n, const double *a, int lda, double *x,
                            int incx, int fpe, int early_exit, int round_mode, hipStream_t st);
 
-hipError_t exgemm_i8(Ctx &c, char transa, char transb, int m, int n, int k, double alpha, const double *a, int lda,
-                     const double *b, int ldb, double beta, double *cmat, int ldc, int round_mode, hipStream_t st,
-                     bool *launched, const int **gate);
+// blas3_i8.hip: the int8 ExGEMM path in two steps (whole operands, then rows of C)
+struct I8Plan {
+    bool ok = false;
+    int m = 0, n = 0, KC = 0, kpasses = 0, dblocks = 0, force_multi = 0, maybe_multi = 0;
+    int *info = nullptr, *EA = nullptr, *EB = nullptr;
+    signed char *PA = nullptr, *PB = nullptr;
+    unsigned long long *W = nullptr;
+    double beta = 0.0;
+    double *c = nullptr;
+    int ldc = 0, round_mode = 0;
+};
+constexpr int I8_INFO_PATH = 7;  // info word holding the device-side decision: 0 scalar kernel, 2 int8 path
+hipError_t exgemm_i8_prepare(Ctx &c, char transa, char transb, int m, int n, int k, double alpha, const double *a, int lda,
+                             const double *b, int ldb, double beta, double *cmat, int ldc, int round_mode,
+                             hipStream_t st, I8Plan *plan);
+hipError_t exgemm_i8_rows(const I8Plan &plan, int row0, int row1, hipStream_t st);
+
+// Row chunks of one exgemm call: the rows [bound[i], bound[i+1]) of C are finished (on the stream) when hook(user, i)
+// is called; bound[0] = 0, bound[n] = m, inner bounds multiples of 64.  Used by the row-sharded GEMM (comm.hip) to
+// ship finished rows while the next chunk is computed.
+struct GemmChunks {
+    int n = 1;
+    int bound[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int (*hook)(void *user, int chunk, hipStream_t st) = nullptr;
+    void *user = nullptr;
+};
+int exgemm_chunked_dev(char transa, char transb, int m, int n, int k, double alpha, const double *d_a, int lda,
+                       const double *d_b, int ldb, double beta, double *d_c, int ldc, int fpe, int early_exit,
+                       hipStream_t st, const GemmChunks *chunks);
 bool exgemm_try_mfma(Ctx &c, char transa, char transb, int m, int n, int k, double alpha, const double *a, int lda,
                      const double *b, int ldb, double beta, double *cmat, int ldc, hipStream_t st, hipError_t *err);
 

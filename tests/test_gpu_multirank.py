@@ -144,6 +144,19 @@ def test_rccl_transport_one_rank():
     got = _run_all(ex, torch, comm, 0, 1)
     for key in one:
         assert got[key] == one[key], key
+    # row chunks: 2200 local rows are produced in 4 chunks (cuts at multiples of 64 rows), each shipped by its own group
+    # of broadcasts on the side stream while the next chunk is computed; operands scanned and sliced once
+    m, n, k = 2200, 96, 130
+    A = ex.gen_dev("fpuniform_signed", m * k, 87, 20, 10)
+    B = ex.gen_dev("fpuniform_signed", k * n, 88, 20, 10)
+    C0 = ex.gen_dev("fpuniform_signed", m * n, 89, 20, 10)
+    for fpe, ee in ((8, True), (0, False)):
+        want_c = C0.clone()
+        ex.exgemm_dev("N", "N", m, n, k, 1.0, A, k, B, n, 1.0, want_c, n, fpe, ee)
+        got_c = C0.clone()
+        ex.exgemm_sharded(comm, m, n, k, 1.0, A, B, 1.0, got_c, fpe, ee)
+        torch.cuda.synchronize()
+        assert torch.equal(want_c.view(torch.int64), got_c.view(torch.int64)), (fpe, ee)
     # graph capture of exsum + all-reduce + finalize
     x = ex.gen_dev("ill_cond", 1 << 20, 3, 1e32)
     rec = ex.new_record_buffer()
