@@ -175,3 +175,13 @@ def test_rccl_transport_one_rank():
     r2 = ex.read_record(rec2)
     assert r2.exact == want.exact and (r2.canon == want.canon).all()
     comm.destroy()
+
+
+def test_standalone_cpp_comm_caller():
+    """tests/cpp/test_comm.cpp: the multi-GPU entry points called from C++ (no Python, no torch in the process) over
+    both transports, bit-identical to the plain single-GPU calls."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["make", "-C", os.path.join(root, "tests", "cpp")], check=True, capture_output=True)
+    r = subprocess.run([os.path.join(root, "tests", "cpp", "test_comm")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "TestPassed; ALL OK!" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
