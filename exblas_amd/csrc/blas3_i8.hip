@@ -43,7 +43,10 @@ typedef int v16i_t __attribute__((ext_vector_type(16)));
 
 constexpr int I8_T = 64;         // tile edge: rows (columns) per tile, and k bytes per chunk
 constexpr int I8_TILE = I8_T * I8_T;  // bytes of one plane of one tile
-constexpr int I8_SMAX = 8;       // digits per operand and pass (15 int32 accumulator groups per wave)
+constexpr int I8_SMAX = 8;       // digits per operand and pass of the generic body and of multi-block operands
+constexpr int I8_XMAX = 9;       // digits per operand and pass the unrolled bodies go up to (17 int32 accumulator
+                                 // tiles = 272 AGPRs per wave + 2 x 18 fragments; 2 x 18 planes x 4 KiB = 144 KiB of LDS;
+                                 // 10 digits would need 304 + 160 registers: it spills)
 constexpr int I8_SCAP = 16;      // digits per operand the path supports (2 x 2 passes)
 constexpr int I8_KPASS = 8192;   // k per pass: 8192 * 8 pairs * 2^14 = 2^30 < 2^31
 constexpr int I8_NWG = 5;        // 64-bit words of the per-entry accumulator in global memory (multi-pass)
@@ -84,10 +87,10 @@ __global__ void k_i8_decide(int *info, int scap)
     int bs = I8_SMAX, exact = 0;
     const int hi = sa > sb ? sa : sb, lo = sa > sb ? sb : sa;
     if (lo >= hi - 1 && hi >= 4) {
-        const int padded = hi <= I8_SMAX ? hi : 2 * ((hi + 1) / 2);
+        const int padded = hi <= I8_XMAX ? hi : 2 * ((hi + 1) / 2);
         if (padded <= scap) {
             sa = sb = padded;
-            bs = padded <= I8_SMAX ? padded : padded / 2;
+            bs = padded <= I8_XMAX ? padded : padded / 2;
             exact = 1;
         }
     }
@@ -402,7 +405,7 @@ __device__ __forceinline__ void i8_epilogue(const PassArgs &a, const v16i_t (&ac
 }
 
 // LDS of one workgroup: [buffer][A planes | B planes][256 x 16 B] = 128 KiB
-typedef v4i_t (*LdsBuf)[2 * I8_SMAX * (I8_TILE / 16)];
+typedef v4i_t (*LdsBuf)[2 * I8_XMAX * (I8_TILE / 16)];
 
 // wait for this wave's LDS traffic, then the workgroup barrier -- without the vmcnt(0) of __syncthreads(): the global
 // loads of the chunk after next stay in flight across it
@@ -413,7 +416,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 //   into one of two register sets while the MFMAs of the previous k-step run; the global loads of chunk kc+2 are issued
 //   right after the registers of chunk kc+1 have been stored to the other LDS buffer, i.e. a full chunk (~4000 cycles)
 //   ahead; one barrier per chunk.
-template <int B>
+template <int B, bool GLDS>
 __device__ __forceinline__ void i8_pass_exact(const PassArgs &a, LdsBuf lds)
 {
     constexpr int G = 2 * B - 1;
@@ -438,7 +441,7 @@ __device__ __forceinline__ void i8_pass_exact(const PassArgs &a, LdsBuf lds)
 #pragma unroll
         for (int p = 0; p < B; ++p) lds[buf][p * 256 + tid] = ra[p];
 #pragma unroll
-        for (int q = 0; q < B; ++q) lds[buf][(I8_SMAX + q) * 256 + tid] = rb[q];
+        for (int q = 0; q < B; ++q) lds[buf][(I8_XMAX + q) * 256 + tid] = rb[q];
     };
     const int arow = wr + (lane & 31), brow = wc + (lane & 31), half = lane >> 5;
     int aoff[2], boff[2];
@@ -449,7 +452,7 @@ __device__ __forceinline__ void i8_pass_exact(const PassArgs &a, LdsBuf lds)
     }
     auto fload = [&](int buf, int ks, v4i_t (&fa)[B], v4i_t (&fb)[B]) {
 #pragma unroll
-        for (int q = 0; q < B; ++q) fb[q] = lds[buf][(I8_SMAX + q) * 256 + boff[ks]];
+        for (int q = 0; q < B; ++q) fb[q] = lds[buf][(I8_XMAX + q) * 256 + boff[ks]];
 #pragma unroll
         for (int p = 0; p < B; ++p) fa[p] = lds[buf][p * 256 + aoff[ks]];
     };
@@ -506,6 +509,62 @@ __device__ __forceinline__ void i8_pass_exact(const PassArgs &a, LdsBuf lds)
     auto clampk = [&](int kc) { return kc < a.kc1 ? kc : a.kc1 - 1; };
 
     v4i_t fa0[B], fb0[B], fa1[B], fb1[B];
+    if constexpr (GLDS) {
+        // LDS-DMA staging (global_load_lds_dwordx4): a wave-instruction copies 64 x 16 B = this wave's quarter of one
+        // 4 KiB plane straight into LDS (the LDS image is lane-linear, exactly the tile-major layout the slicer wrote,
+        // swizzle included), with no staging registers and no ds_write.  Chunk kc+2 is issued into the buffer chunk kc
+        // occupied right after the barrier that retires its last fragment reads, and has a full chunk of MFMAs to
+        // land before the vmcnt(0) + barrier that precedes its first read.
+        auto dma = [&](int kc, int buf) {
+#pragma unroll
+            for (int p = 0; p < B; ++p)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(pa + kc * stride_a + (size_t)p * I8_TILE),
+                                                 (__attribute__((address_space(3))) void *)&lds[buf][p * 256 + wave * 64], 16, 0, 0);
+#pragma unroll
+            for (int q = 0; q < B; ++q)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(pb + kc * stride_b + (size_t)q * I8_TILE),
+                                                 (__attribute__((address_space(3))) void *)&lds[buf][(I8_XMAX + q) * 256 + wave * 64], 16, 0, 0);
+        };
+        // One k-step, in explicit issue order: per group one fragment read for the NEXT k-step, (optionally) one
+        // LDS-DMA piece of chunk kc+2, and the next PER MFMAs of this k-step; a scheduling barrier pins each group
+        // (left alone, the scheduler gathers the DMAs and their M0 writes at one end of the region).
+        auto kstep = [&](const v4i_t (&ca)[B], const v4i_t (&cb)[B], v4i_t (&na)[B], v4i_t (&nb)[B], int rbuf, int rks,
+                         bool with_dma, int dkc, int dbuf) {
+            constexpr int PER = B * B / NMEM, EXTRA = B * B % NMEM;
+            static_for_i8<0, NMEM>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                if constexpr (i < B) nb[i] = lds[rbuf][(I8_XMAX + i) * 256 + boff[rks]];
+                else na[i - B] = lds[rbuf][(i - B) * 256 + aoff[rks]];
+                if (with_dma) {
+                    if constexpr (i < B)
+                        __builtin_amdgcn_global_load_lds(
+                            (const __attribute__((address_space(1))) void *)(pa + dkc * stride_a + (size_t)i * I8_TILE),
+                            (__attribute__((address_space(3))) void *)&lds[dbuf][i * 256 + wave * 64], 16, 0, 0);
+                    else
+                        __builtin_amdgcn_global_load_lds(
+                            (const __attribute__((address_space(1))) void *)(pb + dkc * stride_b + (size_t)(i - B) * I8_TILE),
+                            (__attribute__((address_space(3))) void *)&lds[dbuf][(I8_XMAX + i - B) * 256 + wave * 64], 16, 0, 0);
+                }
+                constexpr int m0 = i * PER + (i < EXTRA ? i : EXTRA), m1 = m0 + PER + (i < EXTRA ? 1 : 0);
+                static_for_i8<m0, m1>([&](auto mc) {
+                    constexpr int mm = decltype(mc)::value, p = mm / B, q = mm % B;
+                    acc[p + q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ca[p], cb[q], acc[p + q], 0, 0, 0);
+                });
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        };
+        dma(a.kc0, 0);
+        __syncthreads();  // vmcnt(0) + lgkmcnt(0) + barrier
+        fload(0, 0, fa0, fb0);
+        dma(clampk(a.kc0 + 1), 1);
+        for (int kc = a.kc0; kc < a.kc1; ++kc) {
+            const int buf = (kc - a.kc0) & 1;
+            kstep(fa0, fb0, fa1, fb1, buf, 1, false, 0, 0);
+            __syncthreads();  // chunk kc+1 has landed in the other buffer; nobody reads this one any more
+            kstep(fa1, fb1, fa0, fb0, buf ^ 1, 0, true, clampk(kc + 2), buf);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped tail loads must not outlive the LDS allocation
+    } else {
     gload(a.kc0);
     lstore(0);
     gload(clampk(a.kc0 + 1));
@@ -523,9 +582,9 @@ __device__ __forceinline__ void i8_pass_exact(const PassArgs &a, LdsBuf lds)
                 if (i < B) {
                     lds[buf ^ 1][i * 256 + tid] = ra[i];
                     ra[i] = *(const v4i_t *)(pa + kn * stride_a + (size_t)i * I8_TILE);
-                    fb1[i] = lds[buf][(I8_SMAX + i) * 256 + boff[1]];
+                    fb1[i] = lds[buf][(I8_XMAX + i) * 256 + boff[1]];
                 } else {
-                    lds[buf ^ 1][(I8_SMAX + i - B) * 256 + tid] = rb[i - B];
+                    lds[buf ^ 1][(I8_XMAX + i - B) * 256 + tid] = rb[i - B];
                     rb[i - B] = *(const v4i_t *)(pb + kn * stride_b + (size_t)(i - B) * I8_TILE);
                     fa1[i - B] = lds[buf][(i - B) * 256 + aoff[1]];
                 }
@@ -538,6 +597,7 @@ __device__ __forceinline__ void i8_pass_exact(const PassArgs &a, LdsBuf lds)
         fload(buf ^ 1, 0, fa0, fb0);
         contract(fa1, fb1);
         interleave_reads();
+    }
     }
     i8_epilogue<G>(a, acc, ty, tx, wr, wc);
 }
@@ -572,7 +632,7 @@ __device__ __forceinline__ void i8_pass_generic(const PassArgs &a, int sa, int s
             if (p < sa) lds[buf][p * 256 + tid] = ra[p];
 #pragma unroll
         for (int q = 0; q < I8_SMAX; ++q)
-            if (q < sb) lds[buf][(I8_SMAX + q) * 256 + tid] = rb[q];
+            if (q < sb) lds[buf][(I8_XMAX + q) * 256 + tid] = rb[q];
     };
     v16i_t acc[G];
 #pragma unroll
@@ -600,7 +660,7 @@ __device__ __forceinline__ void i8_pass_generic(const PassArgs &a, int sa, int s
                 if (p < sa) fa[p] = lds[buf][p * 256 + aoff[ks]];
 #pragma unroll
             for (int q = 0; q < I8_SMAX; ++q)
-                if (q < sb) fb[q] = lds[buf][(I8_SMAX + q) * 256 + boff[ks]];
+                if (q < sb) fb[q] = lds[buf][(I8_XMAX + q) * 256 + boff[ks]];
 #pragma unroll
             for (int p = 0; p < I8_SMAX; ++p) {
                 if (p < sa) {
@@ -619,39 +679,78 @@ __device__ __forceinline__ void i8_pass_generic(const PassArgs &a, int sa, int s
 // One pass: C block (64 x 64 per workgroup) += digits [ta0, ta0+bs) of A  x  digits [tb0, tb0+bs) of B over k chunks
 // [kc0, kc1), where (ta0, tb0) = (ia, ib) * bs and bs is the digit block size the device chose (k_i8_decide).
 // allow_single: with one pass in all this launch rounds and writes C itself; otherwise it adds into W.
-__global__ void __launch_bounds__(256, 1) k_gemm_i8(int m, int n, int ty0, int ty_cnt, int KC, int kc0, int kc1, int ia, int ib,
-                                                    const signed char *__restrict__ PA,
-                                                    const signed char *__restrict__ PB, const int *__restrict__ info,
-                                                    const int *__restrict__ EA, const int *__restrict__ EB,
-                                                    double beta, double *__restrict__ c, long long ldc, int round_mode,
-                                                    int allow_single, unsigned long long *__restrict__ W)
+// Two kernels share the argument list: k_gemm_i8 holds the unrolled bodies (it runs when the decision says "exact":
+// equal digit counts in every pass), k_gemm_i8g the generic body (all other operand pairs); each exits at once when
+// the other one is meant.  They are separate kernels because the generic body's scalar bookkeeping spills thousands of
+// SGPRs into VGPR lanes, which the 9-digit unrolled body (272 accumulator + 144 fragment registers) cannot spare.
+__device__ __forceinline__ bool i8_pass_args(PassArgs &a, const int *info, int m, int n, int ty0, int ty_cnt, int KC, int kc0,
+                                             int kc1, int ia, int ib, const signed char *PA, const signed char *PB,
+                                             const int *EA, const int *EB, double beta, double *c, long long ldc,
+                                             int round_mode, int allow_single, unsigned long long *W, int *sa, int *sb)
 {
-    __shared__ v4i_t lds[2][2 * I8_SMAX * (I8_TILE / 16)];
-    if (info[INFO_PATH] != PATH_I8) return;
-    PassArgs a;
     a.sa_all = info[INFO_SA];
     a.sb_all = info[INFO_SB];
     const int bs = info[INFO_BS];
     a.ta0 = ia * bs;
     a.tb0 = ib * bs;
-    if (a.ta0 >= a.sa_all || a.tb0 >= a.sb_all) return;
-    const int sa = min(bs, a.sa_all - a.ta0), sb = min(bs, a.sb_all - a.tb0);
+    if (a.ta0 >= a.sa_all || a.tb0 >= a.sb_all) return false;
+    *sa = min(bs, a.sa_all - a.ta0);
+    *sb = min(bs, a.sb_all - a.tb0);
     a.m = m; a.n = n; a.KC = KC; a.kc0 = kc0; a.kc1 = kc1; a.ty0 = ty0; a.ty_cnt = ty_cnt;
     a.PA = PA; a.PB = PB; a.EA = EA; a.EB = EB;
     a.beta = beta; a.c = c; a.ldc = ldc; a.round_mode = round_mode; a.W = W;
     a.single = allow_single && a.sa_all <= bs && a.sb_all <= bs;
-    if (info[INFO_EXACT]) {  // sa == sb == bs in every pass
+    return true;
+}
+
+#define I8_PASS_PARAMS                                                                                                  \
+    int m, int n, int ty0, int ty_cnt, int KC, int kc0, int kc1, int ia, int ib, const signed char *__restrict__ PA,     \
+        const signed char *__restrict__ PB, const int *__restrict__ info, const int *__restrict__ EA,                   \
+        const int *__restrict__ EB, double beta, double *__restrict__ c, long long ldc, int round_mode, int allow_single, \
+        unsigned long long *__restrict__ W, int glds
+
+__global__ void __launch_bounds__(256, 1) k_gemm_i8(I8_PASS_PARAMS)
+{
+    __shared__ v4i_t lds[2][2 * I8_XMAX * (I8_TILE / 16)];
+    if (info[INFO_PATH] != PATH_I8 || !info[INFO_EXACT]) return;
+    PassArgs a;
+    int sa, sb;
+    if (!i8_pass_args(a, info, m, n, ty0, ty_cnt, KC, kc0, kc1, ia, ib, PA, PB, EA, EB, beta, c, ldc, round_mode,
+                      allow_single, W, &sa, &sb))
+        return;
+    const int bs = info[INFO_BS];  // sa == sb == bs in every pass
+    if (glds || bs > I8_SMAX) {    // 9 digits exist only with LDS-DMA staging (no registers left to stage through)
         switch (bs) {
-        case 4: i8_pass_exact<4>(a, lds); break;
-        case 5: i8_pass_exact<5>(a, lds); break;
-        case 6: i8_pass_exact<6>(a, lds); break;
-        case 7: i8_pass_exact<7>(a, lds); break;
-        default: i8_pass_exact<8>(a, lds); break;
+        case 4: i8_pass_exact<4, true>(a, lds); break;
+        case 5: i8_pass_exact<5, true>(a, lds); break;
+        case 6: i8_pass_exact<6, true>(a, lds); break;
+        case 7: i8_pass_exact<7, true>(a, lds); break;
+        case 9: i8_pass_exact<9, true>(a, lds); break;
+        default: i8_pass_exact<8, true>(a, lds); break;
         }
     } else {
-        i8_pass_generic(a, sa, sb, lds);
+        switch (bs) {
+        case 4: i8_pass_exact<4, false>(a, lds); break;
+        case 5: i8_pass_exact<5, false>(a, lds); break;
+        case 6: i8_pass_exact<6, false>(a, lds); break;
+        case 7: i8_pass_exact<7, false>(a, lds); break;
+        default: i8_pass_exact<8, false>(a, lds); break;
+        }
     }
 }
+
+__global__ void __launch_bounds__(256, 1) k_gemm_i8g(I8_PASS_PARAMS)
+{
+    __shared__ v4i_t lds[2][2 * I8_XMAX * (I8_TILE / 16)];
+    if (info[INFO_PATH] != PATH_I8 || info[INFO_EXACT]) return;
+    PassArgs a;
+    int sa, sb;
+    if (!i8_pass_args(a, info, m, n, ty0, ty_cnt, KC, kc0, kc1, ia, ib, PA, PB, EA, EB, beta, c, ldc, round_mode,
+                      allow_single, W, &sa, &sb))
+        return;
+    i8_pass_generic(a, sa, sb, lds);
+}
+#undef I8_PASS_PARAMS
 
 // multi-pass epilogue: round the 320-bit accumulators
 __global__ void __launch_bounds__(256) k_i8_finish(int row0, int row1, int n, const int *__restrict__ info,
@@ -768,6 +867,7 @@ hipError_t exgemm_i8_prepare(Ctx &c, char transa, char transb, int m, int n, int
     plan->force_multi = force_multi; plan->maybe_multi = maybe_multi ? 1 : 0;
     plan->info = info; plan->EA = EA; plan->EB = EB; plan->PA = PA; plan->PB = PB; plan->W = W;
     plan->beta = beta; plan->c = cmat; plan->ldc = ldc; plan->round_mode = round_mode;
+    plan->glds = c.variant == 1 ? 0 : 1;  // exblas_set_tuning variant 1: register-staged pass body (A/B)
     c.gemm_info_dev = info;
     return hipGetLastError();
 }
@@ -784,9 +884,14 @@ hipError_t exgemm_i8_rows(const I8Plan &p, int row0, int row1, hipStream_t st)
         const int kc0 = kp * (I8_KPASS / I8_T), kc1 = min(p.KC, kc0 + I8_KPASS / I8_T);
         for (int pa_ = 0; pa_ < p.dblocks; ++pa_)
             for (int pb_ = 0; pb_ < p.dblocks; ++pb_)
+            {
                 hipLaunchKernelGGL(k_gemm_i8, dim3(ty_cnt * gx), dim3(256), 0, st, p.m, p.n, ty0, ty_cnt, p.KC, kc0, kc1,
                                    pa_, pb_, p.PA, p.PB, p.info, p.EA, p.EB, p.beta, p.c, (long long)p.ldc, p.round_mode,
-                                   p.force_multi ? 0 : 1, p.W);
+                                   p.force_multi ? 0 : 1, p.W, p.glds);
+                hipLaunchKernelGGL(k_gemm_i8g, dim3(ty_cnt * gx), dim3(256), 0, st, p.m, p.n, ty0, ty_cnt, p.KC, kc0, kc1,
+                                   pa_, pb_, p.PA, p.PB, p.info, p.EA, p.EB, p.beta, p.c, (long long)p.ldc, p.round_mode,
+                                   p.force_multi ? 0 : 1, p.W, p.glds);
+            }
     }
     if (p.maybe_multi)
         hipLaunchKernelGGL(k_i8_finish, dim3((unsigned)(((long long)(row1 - row0) * p.n + 255) / 256)), dim3(256), 0, st,

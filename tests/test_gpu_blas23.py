@@ -118,6 +118,7 @@ def test_exgemm_slice_paths_are_exact(ex, oracle, m, n, k):
     # name: (A, B, 21-bit fp64 slices [0 = refused], int8 digits of A, of B)
     cases = {
         "fpuniform_r10": (oracle.gen("fpuniform", m * k, 81, 10, 0), oracle.gen("fpuniform", k * n, 82, 10, 0), 3, 8, 8),
+        "fpuniform_r17": (oracle.gen("fpuniform", m * k, 91, 17, 0), oracle.gen("fpuniform", k * n, 92, 17, 0), 4, 9, 9),
         "signed_r20": (oracle.gen("fpuniform_signed", m * k, 83, 20, 10), oracle.gen("fpuniform_signed", k * n, 84, 20, 10), 4, 10, 10),
         "naive": (oracle.gen("naive", m * k, 1), oracle.gen("naive", k * n, 1), 3, 7, 7),
         "small_ints": (rng.integers(-1000, 1000, m * k).astype(np.float64), rng.integers(-1000, 1000, k * n).astype(np.float64), 2, 2, 2),
