@@ -17,7 +17,9 @@
 //      pairs (p, q) with the same p + q share one int32 accumulator tile: |d_p d_q| <= 2^14, at most 8 pairs per
 //      group, k <= 8192 per pass  =>  |sum| <= 2^30: every MFMA partial sum is an exact integer.  The slice counts are
 //      read from device memory; digit pairs beyond (sa, sb) are skipped by wave-uniform scalar branches, so one
-//      instantiation serves every operand width up to 8 digits per pass with exactly sa*sb MFMAs per 32x32x32 block.
+//      generic body serves every operand width up to 8 digits per pass with exactly sa*sb MFMAs per 32x32x32 block; pairs
+//      of (nearly) equal width -- the usual case -- are padded to a common count and run a fully unrolled, LDS-DMA staged,
+//      software-pipelined body (4 .. 9 digits per pass).
 //   4. the 15 group sums of a C entry are added, shifted by 8 bits per group, into a 192-bit two's-complement integer
 //      held in registers: the Kulisch accumulator of that entry, shrunk to the window the scales allow.  Operands
 //      wider than 8 digits (ill-conditioned data: up to 16) or k > 8192 take several passes; each pass adds its
@@ -407,19 +409,24 @@ __device__ __forceinline__ void i8_epilogue(const PassArgs &a, const v16i_t (&ac
 // LDS of one workgroup: [buffer][A planes | B planes][256 x 16 B] = 128 KiB
 typedef v4i_t (*LdsBuf)[2 * I8_XMAX * (I8_TILE / 16)];
 
-// wait for this wave's LDS traffic, then the workgroup barrier -- without the vmcnt(0) of __syncthreads(): the global
-// loads of the chunk after next stay in flight across it
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
 // EXACT body: SA = SB = B digits in this pass, everything unrolled, software-pipelined:
-//   per k chunk (64 bytes = two MFMA k-steps) a wave issues 2 x B*B MFMAs; the fragments of a k-step are read from LDS
-//   into one of two register sets while the MFMAs of the previous k-step run; the global loads of chunk kc+2 are issued
-//   right after the registers of chunk kc+1 have been stored to the other LDS buffer, i.e. a full chunk (~4000 cycles)
-//   ahead; one barrier per chunk.
-template <int B, bool GLDS>
+//   * staging by LDS-DMA (global_load_lds_dwordx4): a wave-instruction copies 64 x 16 B = this wave's quarter of one
+//     4 KiB plane straight into LDS (the LDS image is lane-linear, exactly the tile-major layout the slicer wrote,
+//     swizzle included) -- no staging registers, no ds_write.  Chunk kc+2 is issued into the buffer chunk kc occupied
+//     right after the barrier that retires its last fragment reads, and has a full chunk of MFMAs to land before the
+//     vmcnt(0) + barrier that precedes its first read;
+//   * per k chunk (64 bytes = two MFMA k-steps) a wave issues 2 x B*B MFMAs; the fragments of a k-step are read from
+//     LDS into one of two register sets while the MFMAs of the previous k-step run; one barrier per chunk;
+//   * explicit issue order: per group one fragment read for the NEXT k-step, (in the second k-step) one LDS-DMA piece,
+//     and the next few MFMAs; a scheduling barrier pins each group (left alone, the scheduler gathers the DMAs and
+//     their M0 writes at one end of the region and the matrix pipe idles while they issue).
+// History at 8192^3, 8 x 8 digits: register-staged with ds_write_b128, memory instructions clustered 30.0 ms; one per
+// MFMA gap 25.9-26.9 ms; LDS-DMA 25.8-26.4 ms (5 x 5 digit passes: 47.6 -> 44.8 ms).
+template <int B>
 __device__ __forceinline__ void i8_pass_exact(const PassArgs &a, LdsBuf lds)
 {
     constexpr int G = 2 * B - 1;
+    constexpr int NMEM = 2 * B;  // fragment reads per k-step = LDS-DMA pieces per chunk
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int gx = (a.n + I8_T - 1) / I8_T;
     int ty, tx;
@@ -429,20 +436,6 @@ __device__ __forceinline__ void i8_pass_exact(const PassArgs &a, LdsBuf lds)
     const signed char *pa = a.PA + ((size_t)ty * a.KC * a.sa_all + a.ta0) * I8_TILE + (size_t)tid * 16;
     const signed char *pb = a.PB + ((size_t)tx * a.KC * a.sb_all + a.tb0) * I8_TILE + (size_t)tid * 16;
     const size_t stride_a = (size_t)a.sa_all * I8_TILE, stride_b = (size_t)a.sb_all * I8_TILE;
-
-    v4i_t ra[B], rb[B];
-    auto gload = [&](int kc) {
-#pragma unroll
-        for (int p = 0; p < B; ++p) ra[p] = *(const v4i_t *)(pa + kc * stride_a + (size_t)p * I8_TILE);
-#pragma unroll
-        for (int q = 0; q < B; ++q) rb[q] = *(const v4i_t *)(pb + kc * stride_b + (size_t)q * I8_TILE);
-    };
-    auto lstore = [&](int buf) {
-#pragma unroll
-        for (int p = 0; p < B; ++p) lds[buf][p * 256 + tid] = ra[p];
-#pragma unroll
-        for (int q = 0; q < B; ++q) lds[buf][(I8_XMAX + q) * 256 + tid] = rb[q];
-    };
     const int arow = wr + (lane & 31), brow = wc + (lane & 31), half = lane >> 5;
     int aoff[2], boff[2];
 #pragma unroll
@@ -450,155 +443,60 @@ __device__ __forceinline__ void i8_pass_exact(const PassArgs &a, LdsBuf lds)
         aoff[ks] = tile_off(arow, (2 * ks + half) * 16) >> 4;
         boff[ks] = tile_off(brow, (2 * ks + half) * 16) >> 4;
     }
+    v16i_t acc[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[g][r] = 0;
+    auto clampk = [&](int kc) { return kc < a.kc1 ? kc : a.kc1 - 1; };
+    auto dma_piece = [&](auto ic, int kc, int buf) {
+        constexpr int i = decltype(ic)::value;
+        if constexpr (i < B)
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(pa + kc * stride_a + (size_t)i * I8_TILE),
+                (__attribute__((address_space(3))) void *)&lds[buf][i * 256 + wave * 64], 16, 0, 0);
+        else
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(pb + kc * stride_b + (size_t)(i - B) * I8_TILE),
+                (__attribute__((address_space(3))) void *)&lds[buf][(I8_XMAX + i - B) * 256 + wave * 64], 16, 0, 0);
+    };
+    auto dma = [&](int kc, int buf) { static_for_i8<0, NMEM>([&](auto ic) { dma_piece(ic, kc, buf); }); };
     auto fload = [&](int buf, int ks, v4i_t (&fa)[B], v4i_t (&fb)[B]) {
 #pragma unroll
         for (int q = 0; q < B; ++q) fb[q] = lds[buf][(I8_XMAX + q) * 256 + boff[ks]];
 #pragma unroll
         for (int p = 0; p < B; ++p) fa[p] = lds[buf][p * 256 + aoff[ks]];
     };
-    v16i_t acc[G];
-#pragma unroll
-    for (int g = 0; g < G; ++g)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[g][r] = 0;
-    auto contract = [&](const v4i_t (&fa)[B], const v4i_t (&fb)[B]) {
-#pragma unroll
-        for (int p = 0; p < B; ++p)
-#pragma unroll
-            for (int q = 0; q < B; ++q)
-                acc[p + q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[p], fb[q], acc[p + q], 0, 0, 0);
-    };
-
-    // Instruction order inside a k-step (a wave issues in order, and an MFMA only keeps the matrix pipe busy while the
-    // NEXT instruction is another MFMA or something cheap): after every NM MFMAs one LDS write (chunk kc+1 -> other
-    // buffer), one global load (chunk kc+2 -> staging registers) and one LDS read (fragments of the next k-step).
-    // The loop body is branch-free -- past the last chunk the loads and stores repeat the last chunk into a buffer
-    // nobody reads -- so each half of it is ONE scheduling region the group barriers below can order.
-    constexpr int NMEM = 2 * B;                              // memory instructions of each kind per k-step
-    // k-step 0 carries 3 * NMEM memory instructions, k-step 1 NMEM: one per MFMA gap (an MFMA leaves 24 of its 32
-    // cycles of issue time to other instructions; a ds_write_b128 takes 13 of them), the remaining MFMAs back to back
-    auto interleave_full = [&]() {
-        constexpr int REST = B * B - 3 * NMEM;               // B >= 6: >= 0
-        constexpr int PER = REST > 0 ? REST / NMEM : 0, EXTRA = REST > 0 ? REST % NMEM : 0;
-        static_for_i8<0, NMEM>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            if constexpr (B * B >= 3 * NMEM) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // DS write
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
-                __builtin_amdgcn_sched_group_barrier(0x008, 1 + PER + (i < EXTRA ? 1 : 0), 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
-            } else {  // fewer MFMAs than memory instructions (B = 4, 5): several memory instructions per gap
-                constexpr int NM = (B * B + NMEM - 1) / NMEM;
-                __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
-                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-        });
-    };
-    auto interleave_reads = [&]() {
+    auto kstep = [&](const v4i_t (&ca)[B], const v4i_t (&cb)[B], v4i_t (&na)[B], v4i_t (&nb)[B], int rbuf, int rks,
+                     bool with_dma, int dkc, int dbuf) {
         constexpr int PER = B * B / NMEM, EXTRA = B * B % NMEM;
         static_for_i8<0, NMEM>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
-            __builtin_amdgcn_sched_group_barrier(0x008, PER + (i < EXTRA ? 1 : 0), 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if constexpr (i < B) nb[i] = lds[rbuf][(I8_XMAX + i) * 256 + boff[rks]];
+            else na[i - B] = lds[rbuf][(i - B) * 256 + aoff[rks]];
+            if (with_dma) dma_piece(ic, dkc, dbuf);
+            constexpr int m0 = i * PER + (i < EXTRA ? i : EXTRA), m1 = m0 + PER + (i < EXTRA ? 1 : 0);
+            static_for_i8<m0, m1>([&](auto mc) {
+                constexpr int mm = decltype(mc)::value, p = mm / B, q = mm % B;
+                acc[p + q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ca[p], cb[q], acc[p + q], 0, 0, 0);
+            });
+            __builtin_amdgcn_sched_barrier(0);
         });
     };
-    auto clampk = [&](int kc) { return kc < a.kc1 ? kc : a.kc1 - 1; };
 
     v4i_t fa0[B], fb0[B], fa1[B], fb1[B];
-    if constexpr (GLDS) {
-        // LDS-DMA staging (global_load_lds_dwordx4): a wave-instruction copies 64 x 16 B = this wave's quarter of one
-        // 4 KiB plane straight into LDS (the LDS image is lane-linear, exactly the tile-major layout the slicer wrote,
-        // swizzle included), with no staging registers and no ds_write.  Chunk kc+2 is issued into the buffer chunk kc
-        // occupied right after the barrier that retires its last fragment reads, and has a full chunk of MFMAs to
-        // land before the vmcnt(0) + barrier that precedes its first read.
-        auto dma = [&](int kc, int buf) {
-#pragma unroll
-            for (int p = 0; p < B; ++p)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(pa + kc * stride_a + (size_t)p * I8_TILE),
-                                                 (__attribute__((address_space(3))) void *)&lds[buf][p * 256 + wave * 64], 16, 0, 0);
-#pragma unroll
-            for (int q = 0; q < B; ++q)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(pb + kc * stride_b + (size_t)q * I8_TILE),
-                                                 (__attribute__((address_space(3))) void *)&lds[buf][(I8_XMAX + q) * 256 + wave * 64], 16, 0, 0);
-        };
-        // One k-step, in explicit issue order: per group one fragment read for the NEXT k-step, (optionally) one
-        // LDS-DMA piece of chunk kc+2, and the next PER MFMAs of this k-step; a scheduling barrier pins each group
-        // (left alone, the scheduler gathers the DMAs and their M0 writes at one end of the region).
-        auto kstep = [&](const v4i_t (&ca)[B], const v4i_t (&cb)[B], v4i_t (&na)[B], v4i_t (&nb)[B], int rbuf, int rks,
-                         bool with_dma, int dkc, int dbuf) {
-            constexpr int PER = B * B / NMEM, EXTRA = B * B % NMEM;
-            static_for_i8<0, NMEM>([&](auto ic) {
-                constexpr int i = decltype(ic)::value;
-                if constexpr (i < B) nb[i] = lds[rbuf][(I8_XMAX + i) * 256 + boff[rks]];
-                else na[i - B] = lds[rbuf][(i - B) * 256 + aoff[rks]];
-                if (with_dma) {
-                    if constexpr (i < B)
-                        __builtin_amdgcn_global_load_lds(
-                            (const __attribute__((address_space(1))) void *)(pa + dkc * stride_a + (size_t)i * I8_TILE),
-                            (__attribute__((address_space(3))) void *)&lds[dbuf][i * 256 + wave * 64], 16, 0, 0);
-                    else
-                        __builtin_amdgcn_global_load_lds(
-                            (const __attribute__((address_space(1))) void *)(pb + dkc * stride_b + (size_t)(i - B) * I8_TILE),
-                            (__attribute__((address_space(3))) void *)&lds[dbuf][(I8_XMAX + i - B) * 256 + wave * 64], 16, 0, 0);
-                }
-                constexpr int m0 = i * PER + (i < EXTRA ? i : EXTRA), m1 = m0 + PER + (i < EXTRA ? 1 : 0);
-                static_for_i8<m0, m1>([&](auto mc) {
-                    constexpr int mm = decltype(mc)::value, p = mm / B, q = mm % B;
-                    acc[p + q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ca[p], cb[q], acc[p + q], 0, 0, 0);
-                });
-                __builtin_amdgcn_sched_barrier(0);
-            });
-        };
-        dma(a.kc0, 0);
-        __syncthreads();  // vmcnt(0) + lgkmcnt(0) + barrier
-        fload(0, 0, fa0, fb0);
-        dma(clampk(a.kc0 + 1), 1);
-        for (int kc = a.kc0; kc < a.kc1; ++kc) {
-            const int buf = (kc - a.kc0) & 1;
-            kstep(fa0, fb0, fa1, fb1, buf, 1, false, 0, 0);
-            __syncthreads();  // chunk kc+1 has landed in the other buffer; nobody reads this one any more
-            kstep(fa1, fb1, fa0, fb0, buf ^ 1, 0, true, clampk(kc + 2), buf);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped tail loads must not outlive the LDS allocation
-    } else {
-    gload(a.kc0);
-    lstore(0);
-    gload(clampk(a.kc0 + 1));
-    lds_barrier();
+    dma(a.kc0, 0);
+    __syncthreads();  // vmcnt(0) + lgkmcnt(0) + barrier
     fload(0, 0, fa0, fb0);
+    dma(clampk(a.kc0 + 1), 1);
     for (int kc = a.kc0; kc < a.kc1; ++kc) {
         const int buf = (kc - a.kc0) & 1;
-        // k-step 0.  The other buffer was last read (k-step 1 of the previous chunk) before the previous barrier.
-        // The three memory streams are written interleaved in the source as well: the compiler must assume that an
-        // LDS write and an LDS read may alias (one array, dynamic buffer index) and keeps their relative order.
-        {
-            const int kn = clampk(kc + 2);
-#pragma unroll
-            for (int i = 0; i < NMEM; ++i) {
-                if (i < B) {
-                    lds[buf ^ 1][i * 256 + tid] = ra[i];
-                    ra[i] = *(const v4i_t *)(pa + kn * stride_a + (size_t)i * I8_TILE);
-                    fb1[i] = lds[buf][(I8_XMAX + i) * 256 + boff[1]];
-                } else {
-                    lds[buf ^ 1][(I8_XMAX + i - B) * 256 + tid] = rb[i - B];
-                    rb[i - B] = *(const v4i_t *)(pb + kn * stride_b + (size_t)(i - B) * I8_TILE);
-                    fa1[i - B] = lds[buf][(i - B) * 256 + aoff[1]];
-                }
-            }
-        }
-        contract(fa0, fb0);
-        interleave_full();
-        lds_barrier();
-        // k-step 1, with the fragments of the next chunk's k-step 0 arriving from the buffer just completed
-        fload(buf ^ 1, 0, fa0, fb0);
-        contract(fa1, fb1);
-        interleave_reads();
+        kstep(fa0, fb0, fa1, fb1, buf, 1, false, 0, 0);
+        __syncthreads();  // chunk kc+1 has landed in the other buffer; nobody reads this one any more
+        // past the last chunk the DMA repeats the last chunk into a buffer nobody reads: the loop body stays branch-free
+        kstep(fa1, fb1, fa0, fb0, buf ^ 1, 0, true, clampk(kc + 2), buf);
     }
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped tail loads must not outlive the LDS allocation
     i8_epilogue<G>(a, acc, ty, tx, wr, wc);
 }
 
@@ -707,7 +605,7 @@ __device__ __forceinline__ bool i8_pass_args(PassArgs &a, const int *info, int m
     int m, int n, int ty0, int ty_cnt, int KC, int kc0, int kc1, int ia, int ib, const signed char *__restrict__ PA,     \
         const signed char *__restrict__ PB, const int *__restrict__ info, const int *__restrict__ EA,                   \
         const int *__restrict__ EB, double beta, double *__restrict__ c, long long ldc, int round_mode, int allow_single, \
-        unsigned long long *__restrict__ W, int glds
+        unsigned long long *__restrict__ W
 
 __global__ void __launch_bounds__(256, 1) k_gemm_i8(I8_PASS_PARAMS)
 {
@@ -718,24 +616,13 @@ __global__ void __launch_bounds__(256, 1) k_gemm_i8(I8_PASS_PARAMS)
     if (!i8_pass_args(a, info, m, n, ty0, ty_cnt, KC, kc0, kc1, ia, ib, PA, PB, EA, EB, beta, c, ldc, round_mode,
                       allow_single, W, &sa, &sb))
         return;
-    const int bs = info[INFO_BS];  // sa == sb == bs in every pass
-    if (glds || bs > I8_SMAX) {    // 9 digits exist only with LDS-DMA staging (no registers left to stage through)
-        switch (bs) {
-        case 4: i8_pass_exact<4, true>(a, lds); break;
-        case 5: i8_pass_exact<5, true>(a, lds); break;
-        case 6: i8_pass_exact<6, true>(a, lds); break;
-        case 7: i8_pass_exact<7, true>(a, lds); break;
-        case 9: i8_pass_exact<9, true>(a, lds); break;
-        default: i8_pass_exact<8, true>(a, lds); break;
-        }
-    } else {
-        switch (bs) {
-        case 4: i8_pass_exact<4, false>(a, lds); break;
-        case 5: i8_pass_exact<5, false>(a, lds); break;
-        case 6: i8_pass_exact<6, false>(a, lds); break;
-        case 7: i8_pass_exact<7, false>(a, lds); break;
-        default: i8_pass_exact<8, false>(a, lds); break;
-        }
+    switch (info[INFO_BS]) {  // sa == sb == bs in every pass
+    case 4: i8_pass_exact<4>(a, lds); break;
+    case 5: i8_pass_exact<5>(a, lds); break;
+    case 6: i8_pass_exact<6>(a, lds); break;
+    case 7: i8_pass_exact<7>(a, lds); break;
+    case 9: i8_pass_exact<9>(a, lds); break;
+    default: i8_pass_exact<8>(a, lds); break;
     }
 }
 
@@ -867,7 +754,6 @@ hipError_t exgemm_i8_prepare(Ctx &c, char transa, char transb, int m, int n, int
     plan->force_multi = force_multi; plan->maybe_multi = maybe_multi ? 1 : 0;
     plan->info = info; plan->EA = EA; plan->EB = EB; plan->PA = PA; plan->PB = PB; plan->W = W;
     plan->beta = beta; plan->c = cmat; plan->ldc = ldc; plan->round_mode = round_mode;
-    plan->glds = c.variant == 1 ? 0 : 1;  // exblas_set_tuning variant 1: register-staged pass body (A/B)
     c.gemm_info_dev = info;
     return hipGetLastError();
 }
@@ -887,10 +773,10 @@ hipError_t exgemm_i8_rows(const I8Plan &p, int row0, int row1, hipStream_t st)
             {
                 hipLaunchKernelGGL(k_gemm_i8, dim3(ty_cnt * gx), dim3(256), 0, st, p.m, p.n, ty0, ty_cnt, p.KC, kc0, kc1,
                                    pa_, pb_, p.PA, p.PB, p.info, p.EA, p.EB, p.beta, p.c, (long long)p.ldc, p.round_mode,
-                                   p.force_multi ? 0 : 1, p.W, p.glds);
+                                   p.force_multi ? 0 : 1, p.W);
                 hipLaunchKernelGGL(k_gemm_i8g, dim3(ty_cnt * gx), dim3(256), 0, st, p.m, p.n, ty0, ty_cnt, p.KC, kc0, kc1,
                                    pa_, pb_, p.PA, p.PB, p.info, p.EA, p.EB, p.beta, p.c, (long long)p.ldc, p.round_mode,
-                                   p.force_multi ? 0 : 1, p.W, p.glds);
+                                   p.force_multi ? 0 : 1, p.W);
             }
     }
     if (p.maybe_multi)

@@ -100,7 +100,7 @@ struct I8Plan {
     unsigned long long *W = nullptr;
     double beta = 0.0;
     double *c = nullptr;
-    int ldc = 0, round_mode = 0, glds = 1;
+    int ldc = 0, round_mode = 0;
 };
 constexpr int I8_INFO_PATH = 7;  // info word holding the device-side decision: 0 scalar kernel, 2 int8 path
 hipError_t exgemm_i8_prepare(Ctx &c, char transa, char transb, int m, int n, int k, double alpha, const double *a, int lda,
