@@ -94,6 +94,70 @@ __global__ void __launch_bounds__(GV_BLOCK) k_gemvN_fpe(int m, int n, double alp
     }
 }
 
+// x' = fl(alpha * x), contiguous: what k_gemvN_fpe_sx reads with SCALAR loads
+__global__ void __launch_bounds__(256) k_scale_x(int n, double alpha, const double *__restrict__ x, long long incx,
+                                                 double *__restrict__ xa)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) xa[i] = alpha * x[(long long)i * incx];
+}
+
+// 'N', expansion path, x from SGPRs.  Lanes are ROWS, so x_k is the same for every lane of the wave: the pre-scaled
+// vector is read with scalar loads (one s_load_dwordx16 per 8 columns) and enters the TwoProd as an SGPR operand -- no
+// LDS staging of x, no workgroup barriers, no fragment registers for it.  The early-exit vote is one fp64 compare
+// per residue (the lane masks are OR-ed by the scalar unit).  Otherwise as k_gemvN_fpe (two rows per lane).
+template <int N, bool EE, int U = 8>
+__global__ void __launch_bounds__(GV_BLOCK) k_gemvN_fpe_sx(int m, int n, const double *__restrict__ a, long long lda,
+                                                           const double *__restrict__ xa, int kper,
+                                                           double *__restrict__ part, long long *__restrict__ ws)
+{
+    const int tid = threadIdx.x;
+    const long long r0 = ((long long)blockIdx.x * GV_BLOCK + tid) * 2;
+    const int ks = blockIdx.y, KS = gridDim.y;
+    const int k0 = ks * kper, k1 = min(n, k0 + kper);
+    const bool v0 = r0 < m;
+    double f0[N], f1[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) f0[i] = f1[i] = 0.0;
+    GlobalSink s0{ws + (v0 ? r0 : 0) * SET_WORDS}, s1{ws + (v0 ? r0 + 1 : 0) * SET_WORDS};
+    if (v0) {
+        const double *col = a + r0 + lda * k0;
+        int k = k0;
+        for (; k + U <= k1; k += U, col += lda * U) {
+            double ax[U], ay[U], xs[U];
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const d2_t r = ld2<true>((const d2_t *)(col + lda * j));
+                ax[j] = r.x;
+                ay[j] = r.y;
+                xs[j] = xa[k + j];  // uniform address: scalar load
+            }
+            double p[U], e[U];
+#pragma unroll
+            for (int j = 0; j < U; ++j) p[j] = two_prod(ax[j], xs[j], e[j]);
+            fpe_absorb_prod<N, EE, U, GlobalSink, 1>(f0, p, e, s0);
+#pragma unroll
+            for (int j = 0; j < U; ++j) p[j] = two_prod(ay[j], xs[j], e[j]);
+            fpe_absorb_prod<N, EE, U, GlobalSink, 1>(f1, p, e, s1);
+        }
+        for (; k < k1; ++k, col += lda) {
+            const d2_t r = ld2<true>((const d2_t *)col);
+            const double xv = xa[k];
+            double p[1], e[1];
+            p[0] = two_prod(r.x, xv, e[0]);
+            fpe_absorb_prod<N, false, 1>(f0, p, e, s0);
+            p[0] = two_prod(r.y, xv, e[0]);
+            fpe_absorb_prod<N, false, 1>(f1, p, e, s1);
+        }
+        double *o = part + ((size_t)r0 * KS + ks) * N;
+#pragma unroll
+        for (int i = 0; i < N; ++i) o[i] = f0[i];
+        o = part + ((size_t)(r0 + 1) * KS + ks) * N;
+#pragma unroll
+        for (int i = 0; i < N; ++i) o[i] = f1[i];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // 'N', superaccumulators only (fpe == 0): 64 rows per workgroup, one private LDS column per row
 // (limb-major [limb][row]: the bank depends on the lane only, so the data-dependent limb index never
@@ -191,7 +255,7 @@ __global__ void __launch_bounds__(GV_BLOCK) k_gemv_finish(int rows, int nvals, c
 // ---------------------------------------------------------------------------------------------
 // 'T': y_j = Round(sum_i A(i,j) * fl(alpha*x_i) (+) beta*y_j); column j is contiguous -> ExDOT per workgroup
 // ---------------------------------------------------------------------------------------------
-template <int N, bool EE, int COPIES, int U = 2>
+template <int N, bool EE, int COPIES, int U = 2, int ZM = 0>
 __global__ void __launch_bounds__(GV_BLOCK) k_gemvT(int m, double alpha, const double *__restrict__ a, long long lda,
                                                     const double *__restrict__ x, long long incx, double beta,
                                                     double *__restrict__ y, long long incy, int round_mode,
@@ -242,7 +306,7 @@ __global__ void __launch_bounds__(GV_BLOCK) k_gemvT(int m, double alpha, const d
                     p[2 * u] = two_prod(qa[u].x, alpha * qx[u].x, e[2 * u]);
                     p[2 * u + 1] = two_prod(qa[u].y, alpha * qx[u].y, e[2 * u + 1]);
                 }
-                fpe_absorb_prod_adaptive<N, EE, 2 * U>(f, p, e, sink, bypass);
+                fpe_absorb_prod_adaptive<N, EE, 2 * U, LdsSink<COPIES>, ZM>(f, p, e, sink, bypass);
             };
             fill(0, ra, rx);
             for (long long tt = 0;;) {
@@ -322,7 +386,7 @@ static hipError_t gemvN_fpe(Ctx &c, int m, int n, double alpha, const double *a,
                             double beta, double *y, int incy, int round_mode, hipStream_t st)
 {
     const int gx = (m + 2 * GV_BLOCK - 1) / (2 * GV_BLOCK);
-    const int wg_target = c.num_cu * (c.variant == 3 ? 4 : (c.variant == 4 ? 16 : (c.variant == 5 ? 32 : 8)));
+    const int wg_target = c.num_cu * (c.variant == 3 ? 8 : (c.variant == 4 ? 16 : (c.variant == 5 ? 32 : 4)));  // 4/CU: 1.43 ms, 8: 1.47, 16: 1.5-1.6
     int KS = (wg_target + gx - 1) / gx;
     const int max_ks = (n + 63) / 64;
     if (KS > max_ks) KS = max_ks;
@@ -333,22 +397,30 @@ static hipError_t gemvN_fpe(Ctx &c, int m, int n, double alpha, const double *a,
     KS = (n + kper - 1) / kper;
     const size_t ws_bytes = (size_t)m * SET_WORDS * sizeof(long long);
     const size_t part_bytes = (size_t)m * KS * N * sizeof(double);
+    const size_t xa_bytes = ((size_t)n * sizeof(double) + 255) & ~(size_t)255;
     hipError_t e;
-    char *base = (char *)workspace(c, ws_bytes + part_bytes, st, &e);
+    char *base = (char *)workspace(c, ws_bytes + part_bytes + xa_bytes, st, &e);
     if (!base) return e;
     long long *ws = (long long *)base;
     double *part = (double *)(base + ws_bytes);
+    double *xa = (double *)(base + ws_bytes + part_bytes);
     e = hipMemsetAsync(ws, 0, ws_bytes, st);
     if (e != hipSuccess) return e;
     const bool vec = (m % 2 == 0) && (lda % 2 == 0) && (((uintptr_t)a) & 15u) == 0;
     dim3 grid(gx, KS);
-    if (vec && c.variant == 1)
+    if (vec && c.variant != 1 && c.variant != 2 && c.variant != 6) {
+        // production: x from SGPRs (scalar loads of the pre-scaled vector), early-exit votes by fp64 compares.  Against
+        // the LDS-staged kernel below (variant 6) in one process: 1.40-1.45 ms against 1.41-1.48 at 32768^2
+        hipLaunchKernelGGL(k_scale_x, dim3((n + 255) / 256), dim3(256), 0, st, n, alpha, x, (long long)incx, xa);
+        hipLaunchKernelGGL((k_gemvN_fpe_sx<N, EE, 8>), grid, dim3(GV_BLOCK), 0, st, m, n, a, (long long)lda, xa, kper, part,
+                           ws);
+    } else if (vec && c.variant == 1)
         hipLaunchKernelGGL((k_gemvN_fpe<N, EE, true, 4>), grid, dim3(GV_BLOCK), 0, st, m, n, alpha, a, (long long)lda, x,
                            (long long)incx, kper, part, ws);
     else if (vec && N == 8 && EE && c.variant == 2)
         hipLaunchKernelGGL((k_gemvN_fpe<N, EE, true, 2>), grid, dim3(GV_BLOCK), 0, st, m, n, alpha, a, (long long)lda, x,
                            (long long)incx, kper, part, ws);
-    else if (vec)  // 8 columns per step: 6.06 TB/s vs 5.78 with 4 (tools/tune_gemv.py, 32768^2)
+    else if (vec)  // (variant 6) x staged in LDS; 8 columns per step: 6.06 TB/s vs 5.78 with 4 (tools/tune_gemv.py, 32768^2)
         hipLaunchKernelGGL((k_gemvN_fpe<N, EE, true, 8>), grid, dim3(GV_BLOCK), 0, st, m, n, alpha, a, (long long)lda, x,
                            (long long)incx, kper, part, ws);
     else
@@ -392,8 +464,11 @@ static hipError_t gemvT(Ctx &c, int m, int n, double alpha, const double *a, int
     if (c.variant == 1)
         hipLaunchKernelGGL((k_gemvT<N, EE, COPIES, 2>), dim3(n), dim3(GV_BLOCK), 0, st, m, alpha, a, (long long)lda, x,
                            (long long)incx, beta, y, (long long)incy, round_mode, 0);
-    else
+    else if (c.variant == 6)  // A/B: early-exit votes by integer ORs of the residue words
         hipLaunchKernelGGL((k_gemvT<N, EE, COPIES, 4>), dim3(n), dim3(GV_BLOCK), 0, st, m, alpha, a, (long long)lda, x,
+                           (long long)incx, beta, y, (long long)incy, round_mode, 1);
+    else  // early-exit votes by fp64 compares: 1.58-1.61 ms against 1.64-1.66 at 32768^2
+        hipLaunchKernelGGL((k_gemvT<N, EE, COPIES, 4, 1>), dim3(n), dim3(GV_BLOCK), 0, st, m, alpha, a, (long long)lda, x,
                            (long long)incx, beta, y, (long long)incy, round_mode, 1);
     return hipGetLastError();
 }

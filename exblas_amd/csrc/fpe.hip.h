@@ -185,7 +185,7 @@ __device__ __forceinline__ void fpe_absorb_adaptive(double (&a)[N > 0 ? N : 1], 
 
 // Products: p[j] + e[j] = a_j * b_j exactly (two_prod, NOT the _safe form: the guard handles overflow).
 // The rounding errors enter the expansion at slot max(N-3, 0) like ExDOT.FPE.cl:254.
-template <int N, bool EE, int CNT, class Sink>
+template <int N, bool EE, int CNT, class Sink, int ZM = 0>
 __device__ __forceinline__ bool fpe_absorb_prod(double (&a)[N > 0 ? N : 1], double (&p)[CNT], double (&e)[CNT],
                                                 Sink &sink)
 {
@@ -199,14 +199,14 @@ __device__ __forceinline__ bool fpe_absorb_prod(double (&a)[N > 0 ? N : 1], doub
     } else {
         constexpr int EFROM = (N >= 3) ? N - 3 : 0;
         fpe_guard<CNT>(a[0], p, e, sink);
-        const bool s1 = fpe_cascade<N, EE, CNT>(a, p, 0, sink);
-        const bool s2 = fpe_cascade<N, EE, CNT>(a, e, EFROM, sink);
+        const bool s1 = fpe_cascade<N, EE, CNT, Sink, ZM>(a, p, 0, sink);
+        const bool s2 = fpe_cascade<N, EE, CNT, Sink, ZM>(a, e, EFROM, sink);
         return s1 || s2;
     }
 }
 
 // adaptive form for products (see fpe_absorb_adaptive)
-template <int N, bool EE, int CNT, class Sink>
+template <int N, bool EE, int CNT, class Sink, int ZM = 0>
 __device__ __forceinline__ void fpe_absorb_prod_adaptive(double (&a)[N > 0 ? N : 1], double (&p)[CNT],
                                                          double (&e)[CNT], Sink &sink, Bypass &bp)
 {
@@ -220,7 +220,7 @@ __device__ __forceinline__ void fpe_absorb_prod_adaptive(double (&a)[N > 0 ? N :
                 sink.add(p[j]);
                 if (e[j] != 0.0 && expo_field(p[j]) != 0x7ffu) sink.add(e[j]);
             }
-        } else if (fpe_absorb_prod<N, EE, CNT>(a, p, e, sink)) {
+        } else if (fpe_absorb_prod<N, EE, CNT, Sink, ZM>(a, p, e, sink)) {
             bp.left = bp.span;
             bp.span = min(2 * bp.span + 1, BYPASS_MAX);
         } else {

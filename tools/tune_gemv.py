@@ -6,6 +6,7 @@ import torch
 import exblas_amd as ex
 lg = int(sys.argv[1]) if len(sys.argv) > 1 else 15
 variants = [int(v) for v in (sys.argv[2] if len(sys.argv) > 2 else "0,1,2,3,4,5").split(",")]
+bpcs = [int(v) for v in (sys.argv[3] if len(sys.argv) > 3 else "8").split(",")]
 m = n = 1 << lg
 lib = ex.load_library()
 a = ex.gen_dev("fpuniform", m * n, 1, 10.0, 0.0)
@@ -13,11 +14,13 @@ x = ex.gen_dev("fpuniform", n, 2, 10.0, 0.0)
 y = ex.gen_dev("fpuniform", m, 3, 10.0, 0.0)
 bytes_alg = 8.0 * (m * n + n + 2 * m)
 for trans in ("N", "T"):
-    times = {v: [] for v in variants}
+    cfgs = [(v, b) for v in variants for b in bpcs]
+    times = {c: [] for c in cfgs}
     ref = None
     for r in range(6):
-        for v in variants:
-            lib.exblas_set_tuning(-1, -1, v)
+        for c in cfgs:
+            v = c
+            lib.exblas_set_tuning(c[1], -1, c[0])
             yy = y.clone()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -29,7 +32,7 @@ for trans in ("N", "T"):
             assert torch.equal(ref.view(torch.int64), yy.view(torch.int64)), v
             if r:
                 times[v].append(e0.elapsed_time(e1) / 3)
-    for v in variants:
+    for v in cfgs:
         med = statistics.median(times[v])
         print(f"gemv {trans} v{v}: {med:.3f} ms  {bytes_alg/med/1e6:.0f} GB/s", flush=True)
-lib.exblas_set_tuning(-1, -1, 0)
+lib.exblas_set_tuning(8, -1, 0)
