@@ -352,6 +352,9 @@ def bench_blas23(ex, torch, comm, world, rank):
     return {"exgemv": gv, "exgemm": gm, "extrsv": tv}
 
 
+GEMM_KERNEL = {"mfma_i8_crt": "k_gemm_crt", "mfma_i8": "k_gemm_i8", "mfma_f64": "k_gemm_mfma", "scalar": "k_gemm"}
+
+
 def gemm_path_info(lib):
     """which ExGEMM implementation ran and how many slice products it issued per element pair"""
     info = {"slices": lib.exblas_last_gemm_slices()}
@@ -359,8 +362,12 @@ def gemm_path_info(lib):
         import ctypes as C
         v = (C.c_int * 8)()
         lib.exblas_last_gemm_info(v)
-        info.update({"path": {0: "scalar", 1: "mfma_f64", 2: "mfma_i8"}.get(v[0], str(v[0])), "slices_a": v[1],
-                     "slices_b": v[2], "products_per_pair": v[1] * v[2]})
+        if v[0] == 4:  # residues modulo 8-bit moduli: one int8 GEMM per modulus
+            info.update({"path": "mfma_i8_crt", "bits_a": v[1], "bits_b": v[2], "moduli": v[3],
+                         "products_per_pair": v[3]})
+        else:
+            info.update({"path": {0: "scalar", 1: "mfma_f64", 2: "mfma_i8"}.get(v[0], str(v[0])), "slices_a": v[1],
+                         "slices_b": v[2], "products_per_pair": v[1] * v[2]})
     return info
 
 
@@ -405,6 +412,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     comm = None
+    transport = "native RCCL int64 all-reduce (ncclAllReduce issued by libexblas.so)"
     force_dist = os.environ.get("EXBLAS_BENCH_FORCE_DIST") == "1"  # rehearse the RCCL path with a 1-rank communicator
     if world > 1:
         import torch.distributed as dist
@@ -420,7 +428,25 @@ def main():
         else:
             torch.cuda.set_device(local_rank % torch.cuda.device_count())
             dist.init_process_group(backend)
-        comm = ex.Comm.from_torch()
+        try:
+            comm = ex.Comm.from_torch()
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench] rank {rank}: native communicator could not be created: {e}", file=sys.stderr, flush=True)
+        if backend == "nccl":
+            # every rank must take the same branch: if the RCCL communicator inside libexblas.so failed anywhere, all
+            # ranks fall back to the library's host-callback transport over a gloo group (slower, same bits) and the
+            # JSON line says so -- a number with a caveat beats no number
+            okt = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device="cuda")
+            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+            if int(okt.item()) == 0:
+                if comm is not None:
+                    comm.destroy()
+                comm = ex.Comm.from_torch(dist.new_group(backend="gloo"), transport="host")
+                transport = "host-callback transport over a gloo group (the native RCCL communicator could not be created)"
+        elif comm is None:
+            raise SystemExit("no communicator")
+        else:
+            transport = "host-callback transport (gloo rehearsal)"
     else:
         torch.cuda.set_device(0)
         if force_dist:
@@ -520,7 +546,7 @@ def main():
                                    f"(c={args.p0:g}) per GPU, fpe={args.fpe} early_exit={ee}, "
                                    f"{world}xMI355X, inputs resident in HBM, steps rotate over {nrot} distinct vectors",
                        "elements_per_gpu": n, "fpe": args.fpe, "early_exit": ee,
-                       "parallelism": (f"shard{world}, native RCCL int64 all-reduce of the 576-byte digit set"
+                       "parallelism": (f"shard{world}, 576-byte digit set per step, {transport}"
                                        if world > 1 else "single")},
             "roofline": roof,
             "result": result.exact,
@@ -539,15 +565,14 @@ def main():
             t2 = gm["flop_2mnk"] / (gm["ms"] * 1e-3) / 1e12
             prods = gm.get("products_per_pair") or gm["slices"] ** 2
             issued = t2 * prods
-            peak_issue = I8_MFMA_PEAK_TOPS if gm.get("path") == "mfma_i8" else F64_MFMA_PEAK_TF
+            peak_issue = I8_MFMA_PEAK_TOPS if str(gm.get("path", "")).startswith("mfma_i8") else F64_MFMA_PEAK_TF
             gm["TFLOPs_2mnk"] = t2
             gm["roofline"] = {"bound": "mfma", "achieved": t2, "peak": F64_MFMA_PEAK_TF * world, "unit": "TFLOP/s",
                               "frac": t2 / (F64_MFMA_PEAK_TF * world), "frac_2mnk": t2 / (F64_MFMA_PEAK_TF * world),
                               "mfma_issued_Tops": issued, "mfma_issue_peak_Tops": peak_issue * world,
                               "mfma_util": issued / (peak_issue * world),
-                              "traffic": load_traffic(args.traffic_json, "k_gemm_i8" if gm.get("path") == "mfma_i8"
-                                                      else "k_gemm_mfma"),
-                              "kernel": "k_gemm_i8" if gm.get("path") == "mfma_i8" else "k_gemm_mfma"}
+                              "traffic": load_traffic(args.traffic_json, GEMM_KERNEL.get(gm.get("path"), "k_gemm")),
+                              "kernel": GEMM_KERNEL.get(gm.get("path"), "k_gemm")}
             out["exgemv"] = gv
             out["exgemm"] = gm
             out["extrsv"] = blas23["extrsv"]

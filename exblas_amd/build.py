@@ -18,7 +18,7 @@ INC = os.path.join(os.path.dirname(PKG), "include")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libexblas.so")
 STAMP = os.path.join(LIBDIR, "build.stamp")
-SOURCES = ["blas1.hip", "blas2.hip", "trsv.hip", "blas3.hip", "blas3_mfma.hip", "blas3_i8.hip", "capi.hip", "comm.hip",
+SOURCES = ["blas1.hip", "blas2.hip", "trsv.hip", "blas3.hip", "blas3_mfma.hip", "blas3_i8.hip", "blas3_crt.hip", "capi.hip", "comm.hip",
            "generators.cpp"]
 # -ffp-contract=off is mandatory: TwoSum/TwoProd must not be fused or re-associated.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",

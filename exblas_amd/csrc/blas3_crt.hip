@@ -1,0 +1,604 @@
+// blas3_crt.hip -- ExGEMM on the int8 matrix cores through residue arithmetic (Chinese remainder theorem): the same
+// exact result as blas3_i8.hip with O(bits) instead of O(bits^2) matrix-core work.
+//
+// blas3_i8.hip writes every entry as sa (sb) base-256 digits and contracts all sa*sb digit pairs: 64 int8 products
+// per element pair for 53-bit mantissas with 10 binades of spread.  Here the fixed-point integers X_il = A'_il / 2^ua_i
+// and Y_lj = B_lj / 2^ub_j (|X| < 2^na, |Y| < 2^nb, exact: gemm_scan.hip.h) are reduced modulo L pairwise coprime
+// moduli p_0 = 256, 255, 253, 251, 247, ... (<= 256, so every symmetric residue is an int8):
+//
+//   1. residues (k_crt_residues): x mod p_t for t < L, one int8 plane per modulus, same tile-major layout as the digit
+//      planes.  L is the smallest count with  p_0 ... p_{L-1} > 2 * k * 2^na * 2^nb  >= 2 |sum_l X_il Y_lj|, decided
+//      on the device from the scan (k_crt_decide): 18 moduli where the digit path needs 8 x 8 = 64 products.
+//   2. contract (k_gemm_crt): per modulus ONE plain int8 GEMM on v_mfma_i32_32x32x32_i8, exact in int32
+//      (|residue| <= 128, k <= 8192 per launch: |sum| <= 2^27); longer k runs one launch per 8192, each adding its
+//      residues to those of the earlier ones.  A workgroup owns a 256 x 256 block of one
+//      modulus (each of its 4 waves 128 x 128 = 16 MFMA tiles, 256 accumulator registers), staged by LDS-DMA.
+//   3. reconstruct + round (k_crt_finish): per entry the L residues -> the integer in (-M/2, M/2) by Garner's
+//      mixed-radix algorithm (moduli grouped in threes: 24-bit super-moduli, fp64 modular arithmetic, then a
+//      multi-word Horner sum), then ONE rounding of value * 2^(ua_i + ub_j) with the routines of the digit path
+//      (round-to-nearest-even, or the reference's Round() on the re-cut 41 limbs).
+//
+// Stream-ordered like the digit path: the decision lives in device memory, kernels that are not needed exit at their
+// first instruction.  Inputs the scan rejects (Inf/NaN/subnormal, exponents beyond +-300, more than 126 bits per
+// operand) leave PATH_SCALAR in the info block and the scalar kernel (blas3.hip) runs.
+#include "gemm_fixed.hip.h"
+
+#include <cstdint>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+namespace exb {
+
+constexpr int CRT_LMAX = 39;      // moduli available: 285 bits (126 + 126 bits of operands and k up to 2^31)
+constexpr int CRT_G = 13;         // groups of three moduli
+constexpr int CRT_W32 = 10;       // 32-bit words of the reconstructed integer (320 bits)
+constexpr int CRT_BT = 256;       // block of C per workgroup: 256 x 256
+constexpr int CRT_KPASS = 128;    // k chunks (of 64) per launch: 8192 * 2^14 = 2^27 < 2^31
+
+struct CrtTables {
+    int p[CRT_LMAX];
+    float invp[CRT_LMAX];            // a shade below 1/p: the truncated quotient is never too large
+    unsigned c8[CRT_LMAX][4];        // 256^t mod p for t = 0..15, byte t%4 of word t/4
+    int bits[CRT_LMAX + 1];          // floor(log2(p_0 ... p_{L-1}))
+    double gp[CRT_G][3], gip[CRT_G][3];             // the moduli of group b and their reciprocals
+    double gi01[CRT_G], gi02[CRT_G], gi12[CRT_G];   // p0^-1 mod p1, p0^-1 mod p2, p1^-1 mod p2
+    double P[CRT_G][3], invP[CRT_G][3];             // super-modulus of group b when it holds w + 1 moduli
+    double ginv[CRT_G][CRT_G][3];    // [a][b][w]: (P_a, all three moduli)^-1 mod P_b(w + 1 moduli), a < b
+    unsigned Q[CRT_G][CRT_W32];      // prod_{a < b} P_a
+    unsigned M[CRT_LMAX + 1][CRT_W32], H[CRT_LMAX + 1][CRT_W32];  // M_L = p_0 ... p_{L-1} and floor(M_L / 2) + 1
+};
+
+__device__ CrtTables g_crt;
+
+// ---------------------------------------------------------------------------------------------
+// host: the tables (small-number arithmetic only; checked end to end by the parity tests)
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+long long inv_mod(long long a, long long m)  // a^-1 mod m, gcd(a, m) = 1
+{
+    long long g = m, x = 0, y = 1, aa = ((a % m) + m) % m;
+    while (aa) {
+        const long long q = g / aa;
+        long long t = g - q * aa; g = aa; aa = t;
+        t = x - q * y; x = y; y = t;
+    }
+    return ((x % m) + m) % m;
+}
+
+long long gcd_ll(long long a, long long b) { return b ? gcd_ll(b, a % b) : a; }
+
+struct Big {  // little-endian 32-bit words
+    uint32_t w[CRT_W32 + 2] = {0};
+    void mul_small(uint32_t f)
+    {
+        uint64_t carry = 0;
+        for (auto &x : w) {
+            const uint64_t t = (uint64_t)x * f + carry;
+            x = (uint32_t)t;
+            carry = t >> 32;
+        }
+    }
+    void add_small(uint32_t v)
+    {
+        uint64_t carry = v;
+        for (auto &x : w) {
+            const uint64_t t = (uint64_t)x + carry;
+            x = (uint32_t)t;
+            carry = t >> 32;
+        }
+    }
+    void half()
+    {
+        uint32_t carry = 0;
+        for (int i = CRT_W32 + 1; i >= 0; --i) {
+            const uint32_t nc = w[i] & 1u;
+            w[i] = (w[i] >> 1) | (carry << 31);
+            carry = nc;
+        }
+    }
+    int bitlen() const
+    {
+        for (int i = CRT_W32 + 1; i >= 0; --i)
+            if (w[i]) return 32 * i + 32 - __builtin_clz(w[i]);
+        return 0;
+    }
+};
+
+const CrtTables &crt_tables_host()
+{
+    static CrtTables t;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        memset(&t, 0, sizeof(t));
+        // pairwise coprime moduli, largest first: 256, 255, 253, 251, 247, 241, ...
+        int cnt = 0;
+        for (int c = 256; c > 1 && cnt < CRT_LMAX; --c) {
+            bool ok = true;
+            for (int i = 0; i < cnt; ++i) ok = ok && gcd_ll(c, t.p[i]) == 1;
+            if (ok) t.p[cnt++] = c;
+        }
+        for (int i = 0; i < CRT_LMAX; ++i) {
+            const int p = t.p[i];
+            t.invp[i] = (float)((1.0 / p) * (1.0 - 1.0 / (1 << 22)));
+            long long pw = 1;
+            for (int d = 0; d < 16; ++d) {
+                t.c8[i][d >> 2] |= (unsigned)(pw % p) << (8 * (d & 3));
+                pw = (pw * 256) % p;
+            }
+        }
+        Big mm;
+        mm.w[0] = 1;
+        t.bits[0] = 0;
+        for (int l = 0; l <= CRT_LMAX; ++l) {
+            if (l > 0) mm.mul_small((uint32_t)t.p[l - 1]);
+            t.bits[l] = mm.bitlen() - 1;
+            Big h = mm;
+            h.half();
+            h.add_small(1);
+            for (int i = 0; i < CRT_W32; ++i) {
+                t.M[l][i] = mm.w[i];
+                t.H[l][i] = h.w[i];
+            }
+        }
+        long long Pfull[CRT_G];
+        for (int b = 0; b < CRT_G; ++b) {
+            const long long p0 = t.p[3 * b], p1 = t.p[3 * b + 1], p2 = t.p[3 * b + 2];
+            const long long pp[3] = {p0, p1, p2};
+            for (int j = 0; j < 3; ++j) {
+                t.gp[b][j] = (double)pp[j];
+                t.gip[b][j] = 1.0 / (double)pp[j];
+            }
+            t.gi01[b] = (double)inv_mod(p0, p1);
+            t.gi02[b] = (double)inv_mod(p0, p2);
+            t.gi12[b] = (double)inv_mod(p1, p2);
+            const long long Pw[3] = {p0, p0 * p1, p0 * p1 * p2};
+            for (int w = 0; w < 3; ++w) {
+                t.P[b][w] = (double)Pw[w];
+                t.invP[b][w] = 1.0 / (double)Pw[w];
+            }
+            Pfull[b] = Pw[2];
+        }
+        for (int b = 0; b < CRT_G; ++b)
+            for (int a = 0; a < b; ++a)
+                for (int w = 0; w < 3; ++w) t.ginv[a][b][w] = (double)inv_mod(Pfull[a], (long long)t.P[b][w]);
+        Big q;
+        q.w[0] = 1;
+        for (int b = 0; b < CRT_G; ++b) {
+            for (int i = 0; i < CRT_W32; ++i) t.Q[b][i] = q.w[i];
+            q.mul_small((uint32_t)Pfull[b]);
+        }
+    });
+    return t;
+}
+
+}  // namespace
+
+// copies the tables into the current device's copy of g_crt (context creation: never inside a stream capture)
+hipError_t crt_tables_upload()
+{
+    const CrtTables &t = crt_tables_host();
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_crt), &t, sizeof(t), 0, hipMemcpyHostToDevice);
+}
+
+// ---------------------------------------------------------------------------------------------
+// decide
+// ---------------------------------------------------------------------------------------------
+__global__ void k_crt_decide(int *info, int clog2k, int lcap)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int path = PATH_CRT;
+    if (info[INFO_FLAGS]) path = PATH_SCALAR;  // Inf / NaN / subnormal input
+    const bool nonzero = info[INFO_EMAX] >= info[INFO_EMIN];
+    if (nonzero && (info[INFO_EMIN] < -I8_ERANGE || info[INFO_EMAX] > I8_ERANGE)) path = PATH_SCALAR;
+    const int na = max(info[INFO_NEED_A], 1), nb = max(info[INFO_NEED_B], 1);
+    if (na > 126 || nb > 126) path = PATH_SCALAR;
+    // |sum_l X_il Y_lj| < 2^(na + nb + clog2k) =: 2^B; the residues determine any integer in (-M/2, M/2): M >= 2^(B+1)
+    const int need = na + nb + clog2k + 1;
+    int L = 1;
+    while (L <= lcap && g_crt.bits[L] < need) ++L;
+    if (L > lcap) path = PATH_SCALAR;
+    info[INFO_CRT_L] = L;
+    info[INFO_CRT_NA] = na;
+    info[INFO_CRT_NB] = nb;
+    info[INFO_PATH] = path;
+}
+
+// ---------------------------------------------------------------------------------------------
+// residues
+// ---------------------------------------------------------------------------------------------
+// One workgroup per (64-vector tile, 64-k chunk) as in the digit slicers; a thread holds 16 consecutive k of one vector
+// as magnitudes + signs and walks the moduli: |X| mod p = (sum_t byte_t(|X|) * (256^t mod p)) mod p, four bytes per
+// v_dot4_u32_u8.  CONTIG: element (v, l) at src[v*ld + l] (A for 'N', B for 'T'); else at src[l*ld + v].
+template <bool CONTIG>
+__global__ void __launch_bounds__(256) k_crt_residues(const double *__restrict__ src, long long ld, int nvec, int len,
+                                                      double scale, const int *__restrict__ E,
+                                                      const int *__restrict__ info, int which,
+                                                      signed char *__restrict__ planes, size_t plane_stride)
+{
+    if (info[INFO_PATH] != PATH_CRT) return;
+    const int L = info[INFO_CRT_L], need = info[which ? INFO_CRT_NB : INFO_CRT_NA];
+    const int kc = blockIdx.x, vt = blockIdx.y, KC = gridDim.x;
+    const int r = CONTIG ? (threadIdx.x >> 2) : (threadIdx.x & 63), seg = CONTIG ? (threadIdx.x & 3) : (threadIdx.x >> 6);
+    const int v = vt * I8_T + r, l0 = kc * I8_T + seg * 16;
+    const int u = (v < nvec ? E[v] : 0) - need;
+    const int nw = (need + 31) >> 5;  // 32-bit words of |X| in use (wave-uniform)
+    unsigned w0[16], w1[16], w2[16], w3[16];
+    unsigned negmask = 0;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int l = l0 + e;
+        double x = 0.0;
+        if (v < nvec && l < len) x = scale * (CONTIG ? src[(long long)v * ld + l] : src[(long long)l * ld + v]);
+        const bool neg = x < 0.0;
+        const I128 X = to_fixed(fabs(x), u);
+        w0[e] = (unsigned)X.lo;
+        w1[e] = (unsigned)(X.lo >> 32);
+        w2[e] = (unsigned)X.hi;
+        w3[e] = (unsigned)((unsigned long long)X.hi >> 32);
+        negmask |= (neg ? 1u : 0u) << e;
+    }
+    signed char *tile = planes + ((size_t)vt * KC + kc) * I8_TILE + tile_off(r, seg * 16);
+    for (int t = 0; t < L; ++t) {
+        const unsigned p = (unsigned)g_crt.p[t], hi = (p - 1u) >> 1;
+        const float invp = g_crt.invp[t];
+        const unsigned c0 = g_crt.c8[t][0], c1 = g_crt.c8[t][1], c2 = g_crt.c8[t][2], c3 = g_crt.c8[t][3];
+        union { v4i_t v; signed char b[16]; } pk;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            unsigned s = __builtin_amdgcn_udot4(w0[e], c0, 0u, false);
+            if (nw > 1) s = __builtin_amdgcn_udot4(w1[e], c1, s, false);
+            if (nw > 2) s = __builtin_amdgcn_udot4(w2[e], c2, s, false);
+            if (nw > 3) s = __builtin_amdgcn_udot4(w3[e], c3, s, false);
+            const unsigned q = (unsigned)((float)s * invp);  // s < 2^20: exact float; q = floor(s/p) or one less
+            unsigned rr = s - q * p;
+            rr = min(rr, rr - p);                            // rr >= p  ->  rr - p (unsigned wrap otherwise)
+            int sv = (int)rr - (rr > hi ? (int)p : 0);       // symmetric residue in [-(p-1)/2 .. (p-1)/2], p = 256: [-128, 127]
+            sv = ((negmask >> e) & 1u) ? -sv : sv;           // p = 256: -(-128) wraps to -128 = 128 mod 256
+            pk.b[e] = (signed char)sv;
+        }
+        *(v4i_t *)(tile + (size_t)t * plane_stride) = pk.v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// the contraction: one int8 GEMM per modulus
+// ---------------------------------------------------------------------------------------------
+// Workgroup = (modulus, 256 x 256 block of C); wave (wy, wx) owns the 128 x 128 quarter = 4 x 4 MFMA tiles.  Per 64-byte
+// k chunk the workgroup stages 4 + 4 tile planes of 4 KiB (32 KiB, two buffers) by LDS-DMA, a wave reads 2 x (4 + 4)
+// fragments and issues 2 x 16 MFMAs.  Same pipeline as i8_pass_exact (blas3_i8.hip): fragments of the next k-step and
+// the DMA of chunk kc + 2 are issued between the MFMAs of the current k-step, one barrier per chunk.
+// Result: R[modulus][row / 4][col] = the four residues (rows 4g .. 4g+3, unsigned bytes) of C mod p_t.
+__global__ void __launch_bounds__(256, 1) k_gemm_crt(int n, int row_end, int ty0, int ty_cnt, int gy, int gx, int KC,
+                                                     int kc0, int kc1, const signed char *__restrict__ PA,
+                                                     const signed char *__restrict__ PB,
+                                                     size_t plane_a, size_t plane_b, const int *__restrict__ info,
+                                                     unsigned *__restrict__ R, int m4)
+{
+    __shared__ v4i_t lds[2][8 * 256];
+    if (info[INFO_PATH] != PATH_CRT) return;
+    const int L = info[INFO_CRT_L];
+    const int by_cnt = (ty_cnt + 3) >> 2, bx_cnt = (gx + 3) >> 2, ntiles = by_cnt * bx_cnt;
+    const int mod = blockIdx.x / ntiles;
+    if (mod >= L) return;
+    int by, bx;
+    tile_of_block(blockIdx.x - mod * ntiles, ntiles, by_cnt, bx_cnt, &by, &bx);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wy = wave >> 1, wx = wave & 1, half = lane >> 5;
+    const int p = g_crt.p[mod];
+    const float invp = g_crt.invp[mod];
+
+    const signed char *ga[4], *gb[4];  // wave-uniform tile streams; the lane offset is added at the load
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ta = min(ty0 + by * 4 + i, gy - 1), tb = min(bx * 4 + i, gx - 1);  // ragged edge: a valid tile again
+        ga[i] = PA + (size_t)mod * plane_a + (size_t)ta * KC * I8_TILE;
+        gb[i] = PB + (size_t)mod * plane_b + (size_t)tb * KC * I8_TILE;
+    }
+    const unsigned lane_off = (unsigned)tid * 16u;
+    int fo[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) fo[ks] = tile_off(lane & 31, (2 * ks + half) * 16) >> 4;
+    const int abase = wy * 2 * 256, bbase = (4 + wx * 2) * 256;
+
+    v16i_t acc[16];
+#pragma unroll
+    for (int g = 0; g < 16; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[g][r] = 0;
+
+    auto clampk = [&](int kc) { return kc < kc1 ? kc : kc1 - 1; };
+    auto dma_piece = [&](auto ic, int kc, int buf) {
+        constexpr int i = decltype(ic)::value;
+        const signed char *src = (i < 4 ? ga[i & 3] : gb[i & 3]) + (size_t)kc * I8_TILE + lane_off;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                         (__attribute__((address_space(3))) void *)&lds[buf][i * 256 + wave * 64], 16, 0,
+                                         0);
+    };
+    auto dma = [&](int kc, int buf) { static_for_i8<0, 8>([&](auto ic) { dma_piece(ic, kc, buf); }); };
+    // unit u (32 rows) of this wave's A (B) quarter: tile plane u / 2, rows 32 (u % 2) ..
+    auto fload = [&](int buf, int ks, v4i_t (&fa)[4], v4i_t (&fb)[4]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) fb[q] = lds[buf][bbase + (q >> 1) * 256 + (q & 1) * 128 + fo[ks]];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) fa[q] = lds[buf][abase + (q >> 1) * 256 + (q & 1) * 128 + fo[ks]];
+    };
+    auto kstep = [&](const v4i_t (&ca)[4], const v4i_t (&cb)[4], v4i_t (&na)[4], v4i_t (&nb)[4], int rbuf, int rks,
+                     bool with_dma, int dkc, int dbuf) {
+        static_for_i8<0, 8>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            if constexpr (i < 4) nb[i] = lds[rbuf][bbase + (i >> 1) * 256 + (i & 1) * 128 + fo[rks]];
+            else na[i - 4] = lds[rbuf][abase + ((i - 4) >> 1) * 256 + ((i - 4) & 1) * 128 + fo[rks]];
+            if (with_dma) dma_piece(ic, dkc, dbuf);
+            static_for_i8<2 * i, 2 * i + 2>([&](auto mc) {
+                constexpr int mm = decltype(mc)::value, pu = mm >> 2, qu = mm & 3;
+                acc[mm] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ca[pu], cb[qu], acc[mm], 0, 0, 0);
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+
+    v4i_t fa0[4], fb0[4], fa1[4], fb1[4];
+    dma(kc0, 0);
+    __syncthreads();
+    fload(0, 0, fa0, fb0);
+    dma(clampk(kc0 + 1), 1);
+    for (int kc = kc0; kc < kc1; ++kc) {
+        const int buf = (kc - kc0) & 1;
+        kstep(fa0, fb0, fa1, fb1, buf, 1, false, 0, 0);
+        __syncthreads();
+        kstep(fa1, fb1, fa0, fb0, buf ^ 1, 0, true, clampk(kc + 2), buf);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped tail loads must not outlive the LDS allocation
+
+    // epilogue: residues in [0, p), four rows per 32-bit word.  C layout of the 32x32 MFMA tile: col = lane & 31,
+    // row = 8 * (r / 4) + 4 * (lane / 32) + (r % 4)
+    const int row_base = (ty0 + by * 4) * I8_T + wy * 128, col_base = bx * CRT_BT + wx * 128 + (lane & 31);
+#pragma unroll
+    for (int pu = 0; pu < 4; ++pu)
+#pragma unroll
+        for (int qu = 0; qu < 4; ++qu)
+#pragma unroll
+            for (int a4 = 0; a4 < 4; ++a4) {
+                unsigned word = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int a = acc[pu * 4 + qu][4 * a4 + b];
+                    int rr = a - (int)floorf((float)a * invp) * p;  // quotient off by at most one either way
+                    rr = rr < 0 ? rr + p : rr;
+                    rr = rr >= p ? rr - p : rr;
+                    word |= (unsigned)rr << (8 * b);
+                }
+                const int gi = row_base + pu * 32 + 8 * a4 + 4 * half, gj = col_base + qu * 32;
+                if (gi < row_end && gj < n) {
+                    unsigned *dst = R + ((size_t)mod * m4 + (gi >> 2)) * n + gj;
+                    if (kc0 > 0) {  // a later k block (k > 8192): add to the residues of the earlier ones
+                        const unsigned old = *dst;
+                        unsigned sum = 0;
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) {
+                            unsigned v = ((old >> (8 * b)) & 255u) + ((word >> (8 * b)) & 255u);
+                            v = v >= (unsigned)p ? v - (unsigned)p : v;
+                            sum |= v << (8 * b);
+                        }
+                        word = sum;
+                    }
+                    *dst = word;
+                }
+            }
+}
+
+// ---------------------------------------------------------------------------------------------
+// reconstruct and round
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double crt_dmod(double z, double P, double invP)  // z mod P for |z| < 2^50, P < 2^24
+{
+    const double q = floor(z * invP);
+    double r = fma(-q, P, z);  // exact; q is off by at most one
+    r = r < 0.0 ? r + P : r;
+    r = r >= P ? r - P : r;
+    return r;
+}
+
+// thread = (group of 4 rows, column): the L words R[t][g][j] hold the residues of the 4 entries
+__global__ void __launch_bounds__(256) k_crt_finish(int row0, int row1, int n, const int *__restrict__ info,
+                                                    const int *__restrict__ EA, const int *__restrict__ EB, double beta,
+                                                    double *__restrict__ c, long long ldc, int round_mode,
+                                                    const unsigned *__restrict__ R, int m4)
+{
+    if (info[INFO_PATH] != PATH_CRT) return;
+    const int L = info[INFO_CRT_L], na = info[INFO_CRT_NA], nb = info[INFO_CRT_NB];
+    const long long loc = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int g0 = row0 >> 2, groups = (row1 - row0 + 3) >> 2;
+    if (loc >= (long long)groups * n) return;
+    const int g = g0 + (int)(loc / n), gj = (int)(loc % n);
+    unsigned res[CRT_LMAX];
+#pragma unroll
+    for (int t = 0; t < CRT_LMAX; ++t) res[t] = t < L ? R[((size_t)t * m4 + g) * n + gj] : 0u;
+    const int G = (L + 2) / 3, wlast = L - 3 * (G - 1);  // groups in use; moduli in the last one (1..3)
+    const int ebj = EB[gj] - nb;
+#pragma unroll 1
+    for (int o = 0; o < 4; ++o) {
+        const int gi = 4 * g + o;
+        if (gi >= row1) break;
+        // 1. inside each group: three 8-bit residues -> the residue modulo the group's 24-bit super-modulus
+        double X[CRT_G];
+#pragma unroll
+        for (int b = 0; b < CRT_G; ++b) {
+            X[b] = 0.0;
+            if (b < G) {
+                const int w = b == G - 1 ? wlast : 3;
+                const double r0 = (double)((res[3 * b] >> (8 * o)) & 255u);
+                double x = r0;
+                if (w >= 2) {
+                    const double r1 = (double)((res[3 * b + 1] >> (8 * o)) & 255u);
+                    const double v1 = crt_dmod((r1 - r0) * g_crt.gi01[b], g_crt.gp[b][1], g_crt.gip[b][1]);
+                    x = fma(g_crt.gp[b][0], v1, r0);
+                    if (w >= 3) {
+                        const double r2 = (double)((res[3 * b + 2] >> (8 * o)) & 255u);
+                        const double v2 = crt_dmod(((r2 - r0) * g_crt.gi02[b] - v1) * g_crt.gi12[b], g_crt.gp[b][2],
+                                                   g_crt.gip[b][2]);
+                        x = fma(g_crt.P[b][1], v2, x);
+                    }
+                }
+                X[b] = x;
+            }
+        }
+        // 2. Garner across the groups: mixed-radix digits V_b, value = V_0 + P_0 (V_1 + P_1 (V_2 + ...))
+#pragma unroll
+        for (int b = 1; b < CRT_G; ++b) {
+            if (b < G) {
+                const int w = (b == G - 1 ? wlast : 3) - 1;
+                const double Pb = g_crt.P[b][w], iPb = g_crt.invP[b][w];
+                double t = X[b];
+#pragma unroll
+                for (int a = 0; a < b; ++a) t = crt_dmod((t - X[a]) * g_crt.ginv[a][b][w], Pb, iPb);
+                X[b] = t;
+            }
+        }
+        // 3. the integer: sum_b V_b * (P_0 ... P_{b-1}) in 32-bit words
+        unsigned acc[CRT_W32];
+#pragma unroll
+        for (int i = 0; i < CRT_W32; ++i) acc[i] = 0u;
+#pragma unroll
+        for (int b = 0; b < CRT_G; ++b) {
+            if (b < G) {
+                constexpr int dummy = 0;
+                (void)dummy;
+                const unsigned vb = (unsigned)X[b];
+                unsigned long long carry = 0;
+#pragma unroll
+                for (int i = 0; i < CRT_W32; ++i) {
+                    // Q_b < 2^(24 b): words above that are zero, the running sum stays below 2^(24 (b + 1))
+                    if (32 * i < 24 * (b + 1) + 32) {
+                        const unsigned long long t = (unsigned long long)g_crt.Q[b][i] * vb + acc[i] + carry;
+                        acc[i] = (unsigned)t;
+                        carry = t >> 32;
+                    }
+                }
+            }
+        }
+        // 4. sign: values >= floor(M/2) + 1 stand for value - M
+        {
+            unsigned long long borrow = 0;
+#pragma unroll
+            for (int i = 0; i < CRT_W32; ++i) {
+                const unsigned long long d = (unsigned long long)acc[i] - g_crt.H[L][i] - borrow;
+                borrow = (d >> 32) & 1ull;
+            }
+            if (!borrow) {
+                unsigned long long bw = 0;
+#pragma unroll
+                for (int i = 0; i < CRT_W32; ++i) {
+                    const unsigned long long d = (unsigned long long)acc[i] - g_crt.M[L][i] - bw;
+                    acc[i] = (unsigned)d;
+                    bw = (d >> 32) & 1ull;
+                }
+            }
+        }
+        unsigned long long w5[CRT_W32 / 2];
+#pragma unroll
+        for (int i = 0; i < CRT_W32 / 2; ++i) w5[i] = (unsigned long long)acc[2 * i] | ((unsigned long long)acc[2 * i + 1] << 32);
+        const int u0 = EA[gi] - na + ebj;
+        const double s = round_mode ? wide_round_reference<CRT_W32 / 2>(w5, u0) : wide_round_n<CRT_W32 / 2>(w5, u0);
+        double *cij = c + (long long)gi * ldc + gj;
+        *cij = (beta == 0.0) ? s : beta * (*cij) + s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side: a pure sequence of launches (same two-step shape as the digit path: whole operands, then rows of C)
+// ---------------------------------------------------------------------------------------------
+hipError_t exgemm_crt_prepare(Ctx &c, char transa, char transb, int m, int n, int k, double alpha, const double *a, int lda,
+                              const double *b, int ldb, double beta, double *cmat, int ldc, int round_mode,
+                              hipStream_t st, I8Plan *plan)
+{
+    plan->ok = false;
+    if (k <= 0 || m <= 0 || n <= 0) return hipSuccess;
+    const int ta = (transa == 'T' || transa == 't'), tb = (transb == 'T' || transb == 't');
+    const int gy = (m + I8_T - 1) / I8_T, gx = (n + I8_T - 1) / I8_T, KC = (k + I8_T - 1) / I8_T;
+    int lcap = c.gemm_max_moduli > 0 ? c.gemm_max_moduli : CRT_LMAX;
+    if (lcap > CRT_LMAX) lcap = CRT_LMAX;
+    int clog2k = 0;
+    while ((1ll << clog2k) < (long long)k) ++clog2k;
+    const int m4 = (m + 3) / 4;
+    // workspace: info | EA EB LA LB | residue planes of A | of B | R
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        const size_t o = off;
+        off += (bytes + 255) & ~(size_t)255;
+        return o;
+    };
+    const size_t plane_a = (size_t)gy * KC * I8_TILE, plane_b = (size_t)gx * KC * I8_TILE;
+    const size_t o_info = take(sizeof(int) * INFO_WORDS);
+    const size_t o_e = take(sizeof(int) * 2 * ((size_t)m + n));
+    const size_t o_pa = take(plane_a * lcap);
+    const size_t o_pb = take(plane_b * lcap);
+    const size_t o_r = take((size_t)lcap * m4 * n * sizeof(unsigned));
+    hipError_t e = hipSuccess;
+    char *base = (char *)workspace(c, off, st, &e);
+    if (!base) {
+        if (e == hipErrorStreamCaptureUnsupported) return e;  // the caller must reserve before capturing
+        return hipSuccess;                                    // out of memory: scalar kernel
+    }
+    int *info = (int *)(base + o_info);
+    int *EA = (int *)(base + o_e), *EB = EA + m, *LA = EB + n, *LB = LA + m;
+    signed char *PA = (signed char *)(base + o_pa), *PB = (signed char *)(base + o_pb);
+
+    hipLaunchKernelGGL(k_scan_init, dim3((m + n + 255) / 256), dim3(256), 0, st, m + n, EA, LA, info);
+    const int ysplit = k >= 2048 ? 32 : (k >= 256 ? 8 : 1);
+    if (!ta)
+        hipLaunchKernelGGL(k_scan_contig, dim3(m), dim3(256), 0, st, a, (long long)lda, m, k, alpha, EA, LA, info);
+    else
+        hipLaunchKernelGGL(k_scan_strided, dim3((m + 255) / 256, ysplit), dim3(256), 0, st, a, (long long)lda, m, k, alpha,
+                           EA, LA, info);
+    if (!tb)
+        hipLaunchKernelGGL(k_scan_strided, dim3((n + 255) / 256, ysplit), dim3(256), 0, st, b, (long long)ldb, n, k, 1.0,
+                           EB, LB, info);
+    else
+        hipLaunchKernelGGL(k_scan_contig, dim3(n), dim3(256), 0, st, b, (long long)ldb, n, k, 1.0, EB, LB, info);
+    hipLaunchKernelGGL(k_scan_finish, dim3((m + 255) / 256), dim3(256), 0, st, m, EA, LA, info, INFO_NEED_A);
+    hipLaunchKernelGGL(k_scan_finish, dim3((n + 255) / 256), dim3(256), 0, st, n, EB, LB, info, INFO_NEED_B);
+    hipLaunchKernelGGL(k_crt_decide, dim3(1), dim3(64), 0, st, info, clog2k, lcap);
+
+    if (!ta)
+        hipLaunchKernelGGL((k_crt_residues<true>), dim3(KC, gy), dim3(256), 0, st, a, (long long)lda, m, k, alpha, EA, info,
+                           0, PA, plane_a);
+    else
+        hipLaunchKernelGGL((k_crt_residues<false>), dim3(KC, gy), dim3(256), 0, st, a, (long long)lda, m, k, alpha, EA,
+                           info, 0, PA, plane_a);
+    if (!tb)
+        hipLaunchKernelGGL((k_crt_residues<false>), dim3(KC, gx), dim3(256), 0, st, b, (long long)ldb, n, k, 1.0, EB, info,
+                           1, PB, plane_b);
+    else
+        hipLaunchKernelGGL((k_crt_residues<true>), dim3(KC, gx), dim3(256), 0, st, b, (long long)ldb, n, k, 1.0, EB, info,
+                           1, PB, plane_b);
+    plan->ok = true;
+    plan->crt = true;
+    plan->m = m; plan->n = n; plan->KC = KC;
+    plan->info = info; plan->EA = EA; plan->EB = EB; plan->PA = PA; plan->PB = PB;
+    plan->R = (unsigned *)(base + o_r);
+    plan->plane_a = plane_a; plan->plane_b = plane_b; plan->lcap = lcap; plan->m4 = m4;
+    plan->beta = beta; plan->c = cmat; plan->ldc = ldc; plan->round_mode = round_mode;
+    c.gemm_info_dev = info;
+    return hipGetLastError();
+}
+
+// rows [row0, row1) of C, row0 a multiple of 64
+hipError_t exgemm_crt_rows(const I8Plan &p, int row0, int row1, hipStream_t st)
+{
+    if (row1 <= row0) return hipSuccess;
+    const int gy = (p.m + I8_T - 1) / I8_T, gx = (p.n + I8_T - 1) / I8_T;
+    const int ty0 = row0 / I8_T, ty_cnt = (row1 - row0 + I8_T - 1) / I8_T;
+    const int by_cnt = (ty_cnt + 3) / 4, bx_cnt = (gx + 3) / 4;
+    for (int kc0 = 0; kc0 < p.KC; kc0 += CRT_KPASS)
+        hipLaunchKernelGGL(k_gemm_crt, dim3((unsigned)(p.lcap * by_cnt * bx_cnt)), dim3(256), 0, st, p.n, row1, ty0, ty_cnt,
+                           gy, gx, p.KC, kc0, min(p.KC, kc0 + CRT_KPASS), p.PA, p.PB, p.plane_a, p.plane_b, p.info, p.R,
+                           p.m4);
+    const long long groups = (row1 - row0 + 3) / 4;
+    hipLaunchKernelGGL(k_crt_finish, dim3((unsigned)((groups * p.n + 255) / 256)), dim3(256), 0, st, row0, row1, p.n, p.info,
+                       p.EA, p.EB, p.beta, p.c, (long long)p.ldc, p.round_mode, p.R, p.m4);
+    return hipGetLastError();
+}
+
+}  // namespace exb

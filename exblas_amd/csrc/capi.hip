@@ -109,7 +109,9 @@ Ctx &ctx(int device, int layer)
             c.bpc_heavy = z.bpc_heavy;
             c.ngroups = z.ngroups; c.variant = z.variant; c.gemm_path = z.gemm_path;
             c.gemm_max_slices = z.gemm_max_slices;
+            c.gemm_max_moduli = z.gemm_max_moduli;
         }
+        EXB_CHECK(crt_tables_upload());
         EXB_CHECK(hipMalloc(&c.gacc_all, 2 * sizeof(long long) * NL * c.ngroups));
         EXB_CHECK(hipMemset(c.gacc_all, 0, 2 * sizeof(long long) * NL * c.ngroups));
         EXB_CHECK(hipMalloc(&c.gflags_all, 128));
@@ -366,13 +368,17 @@ int exblas_last_gemm_info(int *out)
     std::lock_guard<std::mutex> lk(c.mu);
     for (int i = 0; i < 8; ++i) out[i] = 0;
     if (c.gemm_info_dev) {
-        int h[8];
+        int h[16];
         if (hipDeviceSynchronize() != hipSuccess) return -1;
         if (hipMemcpy(h, c.gemm_info_dev, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-        out[0] = h[7] == 2 ? 2 : 0;  // INFO_PATH
+        out[0] = (h[7] == 2 || h[7] == 4) ? h[7] : 0;  // INFO_PATH
         if (out[0] == 2) {
             out[1] = h[5];           // INFO_SA
             out[2] = h[6];           // INFO_SB
+        } else if (out[0] == 4) {
+            out[1] = h[11];          // INFO_CRT_NA: bits of the fixed-point entries of A'
+            out[2] = h[12];          // INFO_CRT_NB
+            out[3] = h[10];          // INFO_CRT_L: moduli = int8 GEMMs
         }
     } else if (c.last_gemm_slices > 0) {
         out[0] = 1;
@@ -385,6 +391,7 @@ int exblas_last_gemm_slices(void)
 {
     int v[8];
     if (exblas_last_gemm_info(v) != 0) return -1;
+    if (v[0] == 4) return v[3];  // residue path: the number of moduli (= int8 GEMMs)
     return v[1] > v[2] ? v[1] : v[2];
 }
 

@@ -416,7 +416,7 @@ int exblas_exgemm_sharded_dev(exblas_comm_t *cm, char transa, char transb, int m
     long long r0, r1;
     shard(m, cm->rank, R, &r0, &r1);
     // The operands are scanned and sliced ONCE; the local rows of C are then produced in NCH chunks (boundaries at
-    // multiples of 64 local rows, the tile height of the int8 kernel), and the all-gather of chunk c -- one piece per
+    // multiples of 256 local rows, the block height of the int8 kernels), and the all-gather of chunk c -- one piece per
     // rank -- runs on a side stream while chunk c+1 is computed.  Chunk boundaries are the same function of (m, R) on
     // every rank, so each rank knows every other rank's pieces.
     const bool overlap = multi && cm->kind == 0;
@@ -429,7 +429,7 @@ int exblas_exgemm_sharded_dev(exblas_comm_t *cm, char transa, char transb, int m
         const long long len = a1 - a0;
         auto cut = [&](int i) -> long long {
             if (i >= NCH) return len;
-            const long long v = ((len * i / NCH) + 63) / 64 * 64;
+            const long long v = ((len * i / NCH) + 255) / 256 * 256;
             return v < len ? v : len;
         };
         *lo = a0 + cut(c);

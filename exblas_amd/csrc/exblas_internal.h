@@ -25,9 +25,11 @@ struct Ctx {
     // at its info block (read lazily, with a synchronisation, by exblas_last_gemm_info); otherwise the host knows.
     int last_gemm_slices = 0;  // host-decided paths: 0 scalar kernel; 2..4: fp64-slice MFMA path with that many slices
     const int *gemm_info_dev = nullptr;
-    int gemm_path = 0;       // 0 / 2: int8 slices on the matrix cores when the data qualifies (decided on the device),
-                             // 1: scalar kernel only, 3: fp64 slices on MFMA-F64 (host-decided, synchronises)
+    int gemm_path = 0;       // 0: int8 matrix cores when the data qualifies (decided on the device) -- residues modulo
+                             // 8-bit moduli for min(m, n) >= 192, base-256 digit slices below; 2: digit slices always;
+                             // 4: residues always; 1: scalar kernel only; 3: fp64 slices on MFMA-F64 (host-decided)
     int gemm_max_slices = 0; // 0 = default (16): digits per operand the int8 path reserves workspace for
+    int gemm_max_moduli = 0; // 0 = default (39): moduli the residue path reserves workspace for
     long long *gacc = nullptr;   // ACTIVE accumulator set: [ngroups][NL] int64, zero between calls
     unsigned *gflags = nullptr;  // non-finite input flags of the active set, zero between calls
     // two sets, so that the finalize of step i (side stream) can overlap the streaming kernel of step i+1
@@ -98,6 +100,11 @@ struct I8Plan {
     int *info = nullptr, *EA = nullptr, *EB = nullptr;
     signed char *PA = nullptr, *PB = nullptr;
     unsigned long long *W = nullptr;
+    // residue path (blas3_crt.hip): PA / PB hold one plane per modulus, R the residues of C
+    bool crt = false;
+    unsigned *R = nullptr;
+    size_t plane_a = 0, plane_b = 0;
+    int lcap = 0, m4 = 0;
     double beta = 0.0;
     double *c = nullptr;
     int ldc = 0, round_mode = 0;
@@ -107,6 +114,13 @@ hipError_t exgemm_i8_prepare(Ctx &c, char transa, char transb, int m, int n, int
                              const double *b, int ldb, double beta, double *cmat, int ldc, int round_mode,
                              hipStream_t st, I8Plan *plan);
 hipError_t exgemm_i8_rows(const I8Plan &plan, int row0, int row1, hipStream_t st);
+// blas3_crt.hip: same two steps on residues modulo 8-bit moduli (info word 7 then holds 4)
+hipError_t exgemm_crt_prepare(Ctx &c, char transa, char transb, int m, int n, int k, double alpha, const double *a, int lda,
+                              const double *b, int ldb, double beta, double *cmat, int ldc, int round_mode,
+                              hipStream_t st, I8Plan *plan);
+hipError_t exgemm_crt_rows(const I8Plan &plan, int row0, int row1, hipStream_t st);
+hipError_t crt_tables_upload();  // into the current device's tables; context creation only
+constexpr int CRT_MIN_EDGE = 192;  // gemm_path 0: the residue path serves products with min(m, n) >= this
 
 // Row chunks of one exgemm call: the rows [bound[i], bound[i+1]) of C are finished (on the stream) when hook(user, i)
 // is called; bound[0] = 0, bound[n] = m, inner bounds multiples of 64.  Used by the row-sharded GEMM (comm.hip) to

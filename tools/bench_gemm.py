@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""ExGEMM timing by path: int8 slices (0), fp64 slices on MFMA-F64 (3), scalar kernel (1).
+"""ExGEMM timing by path: automatic (0: residues for min(m, n) >= 192), int8 residues (4), int8 digit slices (2),
+fp64 slices on MFMA-F64 (3), scalar kernel (1).
 usage: python tools/bench_gemm.py n [rows] [paths e.g. 0,3,1] [kind p0 p1]"""
 import ctypes as C
 import json, os, sys
@@ -35,7 +36,9 @@ for rnd in range(rounds):
         lib.exblas_last_gemm_info(v)
         key = f"path{path}"
         res.setdefault(key, []).append(ms)
-        print(key, f"{ms:.3f} ms, {fl/ms/1e9:.2f} TFLOP/s (2mnk), impl={v[0]} slices={v[1]}x{v[2]}, "
-                   f"issued {fl*v[1]*v[2]/ms/1e9 if v[1] else 0:.1f} Top/s, checksum {float(Cm.sum()):.6e}", flush=True)
+        prods = v[3] if v[0] == 4 else v[1] * v[2]
+        what = f"bits={v[1]}+{v[2]} moduli={v[3]}" if v[0] == 4 else f"slices={v[1]}x{v[2]}"
+        print(key, f"{ms:.3f} ms, {fl/ms/1e9:.2f} TFLOP/s (2mnk), impl={v[0]} {what}, "
+                   f"issued {fl*prods/ms/1e9:.1f} Top/s, checksum {float(Cm.sum()):.6e}", flush=True)
 lib.exblas_set_gemm_path(0)
 print(json.dumps({k: min(v) for k, v in res.items()}))
