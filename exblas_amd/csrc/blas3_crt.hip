@@ -7,15 +7,15 @@
 // moduli p_0 = 256, 255, 253, 251, 247, ... (<= 256, so every symmetric residue is an int8):
 //
 //   1. residues (k_crt_residues): x mod p_t for t < L, one int8 plane per modulus, same tile-major layout as the digit
-//      planes.  L is the smallest count with  p_0 ... p_{L-1} > 2 * k * 2^na * 2^nb  >= 2 |sum_l X_il Y_lj|, decided
+//      planes.  L is the smallest count with  p_0 ... p_{L-1} >= 4 * k * 2^na * 2^nb  > 4 |sum_l X_il Y_lj|, decided
 //      on the device from the scan (k_crt_decide): 18 moduli where the digit path needs 8 x 8 = 64 products.
 //   2. contract (k_gemm_crt): per modulus ONE plain int8 GEMM on v_mfma_i32_32x32x32_i8, exact in int32
 //      (|residue| <= 128, k <= 8192 per launch: |sum| <= 2^27); longer k runs one launch per 8192, each adding its
 //      residues to those of the earlier ones.  A workgroup owns a 256 x 256 block of one
-//      modulus (each of its 4 waves 128 x 128 = 16 MFMA tiles, 256 accumulator registers), staged by LDS-DMA.
-//   3. reconstruct + round (k_crt_finish): per entry the L residues -> the integer in (-M/2, M/2) by Garner's
-//      mixed-radix algorithm (moduli grouped in threes: 24-bit super-moduli, fp64 modular arithmetic, then a
-//      multi-word Horner sum), then ONE rounding of value * 2^(ua_i + ub_j) with the routines of the digit path
+//      modulus (each of its 4 waves 128 x 128 = 16 MFMA tiles, 256 accumulator registers), staged through registers.
+//   3. reconstruct + round (k_crt_finish): per entry the L residues -> the integer in (-M/4, M/4) (moduli grouped in
+//      threes: Garner inside a group in fp64 modular arithmetic, the classical CRT sum across the 24-bit
+//      super-moduli in 32-bit words), then ONE rounding of value * 2^(ua_i + ub_j) with the routines of the digit path
 //      (round-to-nearest-even, or the reference's Round() on the re-cut 41 limbs).
 //
 // Stream-ordered like the digit path: the decision lives in device memory, kernels that are not needed exit at their
@@ -40,13 +40,14 @@ struct CrtTables {
     int p[CRT_LMAX];
     float invp[CRT_LMAX];            // a shade below 1/p: the truncated quotient is never too large
     unsigned c8[CRT_LMAX][4];        // 256^t mod p for t = 0..15, byte t%4 of word t/4
-    int bits[CRT_LMAX + 1];          // floor(log2(p_0 ... p_{L-1}))
+    int bits[CRT_LMAX + 1];          // floor(log2(M_L)), M_L = p_0 ... p_{L-1}
     double gp[CRT_G][3], gip[CRT_G][3];             // the moduli of group b and their reciprocals
     double gi01[CRT_G], gi02[CRT_G], gi12[CRT_G];   // p0^-1 mod p1, p0^-1 mod p2, p1^-1 mod p2
     double P[CRT_G][3], invP[CRT_G][3];             // super-modulus of group b when it holds w + 1 moduli
-    double ginv[CRT_G][CRT_G][3];    // [a][b][w]: (P_a, all three moduli)^-1 mod P_b(w + 1 moduli), a < b
-    unsigned Q[CRT_G][CRT_W32];      // prod_{a < b} P_a
-    unsigned M[CRT_LMAX + 1][CRT_W32], H[CRT_LMAX + 1][CRT_W32];  // M_L = p_0 ... p_{L-1} and floor(M_L / 2) + 1
+    // with L moduli in use (the last group then holds L - 3 (G - 1) of its three):
+    double wc[CRT_LMAX + 1][CRT_G];                 // (M_L / P_b)^-1 mod P_b
+    unsigned MP[CRT_LMAX + 1][CRT_G][CRT_W32];      // M_L / P_b
+    unsigned M[CRT_LMAX + 1][CRT_W32];              // M_L
 };
 
 __device__ CrtTables g_crt;
@@ -98,6 +99,22 @@ struct Big {  // little-endian 32-bit words
             carry = nc;
         }
     }
+    uint32_t div_small(uint32_t d)  // in place; returns the remainder
+    {
+        uint64_t rem = 0;
+        for (int i = CRT_W32 + 1; i >= 0; --i) {
+            const uint64_t cur = (rem << 32) | w[i];
+            w[i] = (uint32_t)(cur / d);
+            rem = cur % d;
+        }
+        return (uint32_t)rem;
+    }
+    uint32_t mod_small(uint32_t d) const
+    {
+        uint64_t rem = 0;
+        for (int i = CRT_W32 + 1; i >= 0; --i) rem = ((rem << 32) | w[i]) % d;
+        return (uint32_t)rem;
+    }
     int bitlen() const
     {
         for (int i = CRT_W32 + 1; i >= 0; --i)
@@ -128,21 +145,6 @@ const CrtTables &crt_tables_host()
                 pw = (pw * 256) % p;
             }
         }
-        Big mm;
-        mm.w[0] = 1;
-        t.bits[0] = 0;
-        for (int l = 0; l <= CRT_LMAX; ++l) {
-            if (l > 0) mm.mul_small((uint32_t)t.p[l - 1]);
-            t.bits[l] = mm.bitlen() - 1;
-            Big h = mm;
-            h.half();
-            h.add_small(1);
-            for (int i = 0; i < CRT_W32; ++i) {
-                t.M[l][i] = mm.w[i];
-                t.H[l][i] = h.w[i];
-            }
-        }
-        long long Pfull[CRT_G];
         for (int b = 0; b < CRT_G; ++b) {
             const long long p0 = t.p[3 * b], p1 = t.p[3 * b + 1], p2 = t.p[3 * b + 2];
             const long long pp[3] = {p0, p1, p2};
@@ -158,16 +160,22 @@ const CrtTables &crt_tables_host()
                 t.P[b][w] = (double)Pw[w];
                 t.invP[b][w] = 1.0 / (double)Pw[w];
             }
-            Pfull[b] = Pw[2];
         }
-        for (int b = 0; b < CRT_G; ++b)
-            for (int a = 0; a < b; ++a)
-                for (int w = 0; w < 3; ++w) t.ginv[a][b][w] = (double)inv_mod(Pfull[a], (long long)t.P[b][w]);
-        Big q;
-        q.w[0] = 1;
-        for (int b = 0; b < CRT_G; ++b) {
-            for (int i = 0; i < CRT_W32; ++i) t.Q[b][i] = q.w[i];
-            q.mul_small((uint32_t)Pfull[b]);
+        Big mm;
+        mm.w[0] = 1;
+        for (int l = 0; l <= CRT_LMAX; ++l) {
+            if (l > 0) mm.mul_small((uint32_t)t.p[l - 1]);
+            t.bits[l] = mm.bitlen() - 1;
+            for (int i = 0; i < CRT_W32; ++i) t.M[l][i] = mm.w[i];
+            const int G = (l + 2) / 3;
+            for (int b = 0; b < G; ++b) {
+                const int w = b == G - 1 ? l - 3 * (G - 1) : 3;
+                const uint32_t Pb = (uint32_t)t.P[b][w - 1];
+                Big q = mm;
+                q.div_small(Pb);  // exact
+                for (int i = 0; i < CRT_W32; ++i) t.MP[l][b][i] = q.w[i];
+                t.wc[l][b] = (double)inv_mod((long long)q.mod_small(Pb), (long long)Pb);
+            }
         }
     });
     return t;
@@ -194,8 +202,9 @@ __global__ void k_crt_decide(int *info, int clog2k, int lcap)
     if (nonzero && (info[INFO_EMIN] < -I8_ERANGE || info[INFO_EMAX] > I8_ERANGE)) path = PATH_SCALAR;
     const int na = max(info[INFO_NEED_A], 1), nb = max(info[INFO_NEED_B], 1);
     if (na > 126 || nb > 126) path = PATH_SCALAR;
-    // |sum_l X_il Y_lj| < 2^(na + nb + clog2k) =: 2^B; the residues determine any integer in (-M/2, M/2): M >= 2^(B+1)
-    const int need = na + nb + clog2k + 1;
+    // |sum_l X_il Y_lj| < 2^(na + nb + clog2k) =: 2^B.  M >= 2^(B+2) keeps value / M inside (-1/4, 1/4), which is what
+    // lets k_crt_finish find the multiple of M to subtract from a floating-point sum of fractions (error << 1/4)
+    const int need = na + nb + clog2k + 2;
     int L = 1;
     while (L <= lcap && g_crt.bits[L] < need) ++L;
     if (L > lcap) path = PATH_SCALAR;
@@ -266,17 +275,18 @@ __global__ void __launch_bounds__(256) k_crt_residues(const double *__restrict__
 // the contraction: one int8 GEMM per modulus
 // ---------------------------------------------------------------------------------------------
 // Workgroup = (modulus, 256 x 256 block of C); wave (wy, wx) owns the 128 x 128 quarter = 4 x 4 MFMA tiles.  Per 64-byte
-// k chunk the workgroup stages 4 + 4 tile planes of 4 KiB (32 KiB, two buffers) by LDS-DMA, a wave reads 2 x (4 + 4)
-// fragments and issues 2 x 16 MFMAs.  Same pipeline as i8_pass_exact (blas3_i8.hip): fragments of the next k-step and
-// the DMA of chunk kc + 2 are issued between the MFMAs of the current k-step, one barrier per chunk.
+// k chunk the workgroup stages 4 + 4 tile planes of 4 KiB (32 KiB, three stages), a wave reads 2 x (4 + 4) fragments
+// and issues 2 x 16 MFMAs; the fragments of the next k-step and one staging instruction are issued between the MFMAs
+// of the current k-step, one barrier per chunk.
 // Result: R[modulus][row / 4][col] = the four residues (rows 4g .. 4g+3, unsigned bytes) of C mod p_t.
+template <int DBG>
 __global__ void __launch_bounds__(256, 1) k_gemm_crt(int n, int row_end, int ty0, int ty_cnt, int gy, int gx, int KC,
                                                      int kc0, int kc1, const signed char *__restrict__ PA,
                                                      const signed char *__restrict__ PB,
                                                      size_t plane_a, size_t plane_b, const int *__restrict__ info,
-                                                     unsigned *__restrict__ R, int m4)
+                                                     unsigned *__restrict__ R, int m4, int dbg)
 {
-    __shared__ v4i_t lds[2][8 * 256];
+    __shared__ v4i_t lds[3][8 * 256];
     if (info[INFO_PATH] != PATH_CRT) return;
     const int L = info[INFO_CRT_L];
     const int by_cnt = (ty_cnt + 3) >> 2, bx_cnt = (gx + 3) >> 2, ntiles = by_cnt * bx_cnt;
@@ -284,6 +294,10 @@ __global__ void __launch_bounds__(256, 1) k_gemm_crt(int n, int row_end, int ty0
     if (mod >= L) return;
     int by, bx;
     tile_of_block(blockIdx.x - mod * ntiles, ntiles, by_cnt, bx_cnt, &by, &bx);
+    if (dbg == 2) {
+        by = (blockIdx.x - mod * ntiles) / bx_cnt;
+        bx = (blockIdx.x - mod * ntiles) % bx_cnt;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wy = wave >> 1, wx = wave & 1, half = lane >> 5;
     const int p = g_crt.p[mod];
     const float invp = g_crt.invp[mod];
@@ -307,15 +321,23 @@ __global__ void __launch_bounds__(256, 1) k_gemm_crt(int n, int row_end, int ty0
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[g][r] = 0;
 
-    auto clampk = [&](int kc) { return kc < kc1 ? kc : kc1 - 1; };
-    auto dma_piece = [&](auto ic, int kc, int buf) {
-        constexpr int i = decltype(ic)::value;
-        const signed char *src = (i < 4 ? ga[i & 3] : gb[i & 3]) + (size_t)kc * I8_TILE + lane_off;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                         (__attribute__((address_space(3))) void *)&lds[buf][i * 256 + wave * 64], 16, 0,
-                                         0);
+    auto clampk = [&](int kc) { return dbg == 1 ? kc0 : (kc < kc1 ? kc : kc1 - 1); };
+    // Staging through registers: global_load_dwordx4 -> (two chunks later) ds_write_b128.  An LDS-DMA piece costs the
+    // issuing wave 100-185 cycles beside this many fragment reads (MI355X_MICROARCH.md, 'LDS-DMA piece issue cost'),
+    // and a chunk of 2 x 16 MFMAs needs 8 pieces per wave every ~1000 cycles: with DMA staging the matrix pipe was
+    // 55-58 % busy.  Chunk c lives in LDS stage c % 3 and, before that, in register set c % 3; in iteration i (chunk
+    // i): MFMAs of chunk i, fragment reads for the next k-step, ds_write of chunk i + 2 (set -> stage (i + 2) % 3, free
+    // since the barrier of iteration i - 1), global loads of chunk i + 4 into the set chunk i + 1 left.  One barrier
+    // per chunk, LDS traffic only (no vmcnt wait: the loads in flight belong to later chunks).
+    v4i_t st[3][8];
+    auto gload = [&](auto sc, auto jc, int kc) {
+        constexpr int sidx = decltype(sc)::value, j = decltype(jc)::value;
+        st[sidx][j] = *(const v4i_t *)((j < 4 ? ga[j & 3] : gb[j & 3]) + (size_t)clampk(kc) * I8_TILE + lane_off);
     };
-    auto dma = [&](int kc, int buf) { static_for_i8<0, 8>([&](auto ic) { dma_piece(ic, kc, buf); }); };
+    auto lwrite = [&](auto sc, auto jc) {  // set s -> stage s, lane-linear image of the 4 KiB tile plane
+        constexpr int sidx = decltype(sc)::value, j = decltype(jc)::value;
+        lds[sidx][j * 256 + tid] = st[sidx][j];
+    };
     // unit u (32 rows) of this wave's A (B) quarter: tile plane u / 2, rows 32 (u % 2) ..
     auto fload = [&](int buf, int ks, v4i_t (&fa)[4], v4i_t (&fb)[4]) {
 #pragma unroll
@@ -323,13 +345,26 @@ __global__ void __launch_bounds__(256, 1) k_gemm_crt(int n, int row_end, int ty0
 #pragma unroll
         for (int q = 0; q < 4; ++q) fa[q] = lds[buf][abase + (q >> 1) * 256 + (q & 1) * 128 + fo[ks]];
     };
-    auto kstep = [&](const v4i_t (&ca)[4], const v4i_t (&cb)[4], v4i_t (&na)[4], v4i_t (&nb)[4], int rbuf, int rks,
-                     bool with_dma, int dkc, int dbuf) {
+    // one k-step (16 MFMAs) of chunk kc, residue class r = (kc - kc0) % 3; h = 0: first k-step (the fragments of the
+    // second are read meanwhile), h = 1: second (fragments of the next chunk's first).  Explicit issue order: per
+    // group one fragment read, one staging instruction (a store of chunk kc + 2 or a load of chunk kc + 4, alternating)
+    // and two MFMAs; a scheduling barrier pins each group.
+    auto khalf = [&](auto hc, auto rc, const v4i_t (&ca)[4], const v4i_t (&cb)[4], v4i_t (&na)[4], v4i_t (&nb)[4], int kc) {
+        constexpr int h = decltype(hc)::value, r = decltype(rc)::value;
+        constexpr int rstage = h == 0 ? r : (r + 1) % 3, rks = h == 0 ? 1 : 0;
+        constexpr int wset = (r + 2) % 3, lset = (r + 1) % 3;
         static_for_i8<0, 8>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
-            if constexpr (i < 4) nb[i] = lds[rbuf][bbase + (i >> 1) * 256 + (i & 1) * 128 + fo[rks]];
-            else na[i - 4] = lds[rbuf][abase + ((i - 4) >> 1) * 256 + ((i - 4) & 1) * 128 + fo[rks]];
-            if (with_dma) dma_piece(ic, dkc, dbuf);
+            if constexpr (DBG < 5) {
+                if constexpr (i < 4) nb[i] = lds[rstage][bbase + (i >> 1) * 256 + (i & 1) * 128 + fo[rks]];
+                else na[i - 4] = lds[rstage][abase + ((i - 4) >> 1) * 256 + ((i - 4) & 1) * 128 + fo[rks]];
+            } else {
+                if constexpr (i < 4) nb[i] = cb[i]; else na[i - 4] = ca[i - 4];
+            }
+            if constexpr (DBG < 3) {
+                if constexpr (i & 1) lwrite(std::integral_constant<int, wset>{}, std::integral_constant<int, h * 4 + i / 2>{});
+                else gload(std::integral_constant<int, lset>{}, std::integral_constant<int, h * 4 + i / 2>{}, kc + 4);
+            }
             static_for_i8<2 * i, 2 * i + 2>([&](auto mc) {
                 constexpr int mm = decltype(mc)::value, pu = mm >> 2, qu = mm & 3;
                 acc[mm] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ca[pu], cb[qu], acc[mm], 0, 0, 0);
@@ -339,17 +374,32 @@ __global__ void __launch_bounds__(256, 1) k_gemm_crt(int n, int row_end, int ty0
     };
 
     v4i_t fa0[4], fb0[4], fa1[4], fb1[4];
-    dma(kc0, 0);
-    __syncthreads();
+    auto body = [&](auto rc, int kc) {
+        khalf(std::integral_constant<int, 0>{}, rc, fa0, fb0, fa1, fb1, kc);
+        // the stores of chunk kc+1 (previous iteration) and the first half of chunk kc+2 are visible after this; nobody
+        // reads stage r any more
+        if constexpr (DBG < 4) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        khalf(std::integral_constant<int, 1>{}, rc, fa1, fb1, fa0, fb0, kc);
+    };
+    // prologue: chunks 0 and 1 through registers into stages 0 and 1, chunks 2 and 3 into sets 2 and 0
+    static_for_i8<0, 8>([&](auto jc) { gload(std::integral_constant<int, 0>{}, jc, kc0); });
+    static_for_i8<0, 8>([&](auto jc) { gload(std::integral_constant<int, 1>{}, jc, kc0 + 1); });
+    static_for_i8<0, 8>([&](auto jc) { lwrite(std::integral_constant<int, 0>{}, jc); });
+    static_for_i8<0, 8>([&](auto jc) { lwrite(std::integral_constant<int, 1>{}, jc); });
+    static_for_i8<0, 8>([&](auto jc) { gload(std::integral_constant<int, 2>{}, jc, kc0 + 2); });
+    static_for_i8<0, 8>([&](auto jc) { gload(std::integral_constant<int, 0>{}, jc, kc0 + 3); });
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     fload(0, 0, fa0, fb0);
-    dma(clampk(kc0 + 1), 1);
-    for (int kc = kc0; kc < kc1; ++kc) {
-        const int buf = (kc - kc0) & 1;
-        kstep(fa0, fb0, fa1, fb1, buf, 1, false, 0, 0);
-        __syncthreads();
-        kstep(fa1, fb1, fa0, fb0, buf ^ 1, 0, true, clampk(kc + 2), buf);
+    int kc = kc0;
+    for (; kc + 3 <= kc1; kc += 3) {  // branch-free: a merge inside would make the register sets wait for their loads
+        body(std::integral_constant<int, 0>{}, kc);
+        body(std::integral_constant<int, 1>{}, kc + 1);
+        body(std::integral_constant<int, 2>{}, kc + 2);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped tail loads must not outlive the LDS allocation
+    if (kc < kc1) {
+        body(std::integral_constant<int, 0>{}, kc);
+        if (kc + 1 < kc1) body(std::integral_constant<int, 1>{}, kc + 1);
+    }
 
     // epilogue: residues in [0, p), four rows per 32-bit word.  C layout of the 32x32 MFMA tile: col = lane & 31,
     // row = 8 * (r / 4) + 4 * (lane / 32) + (r % 4)
@@ -400,7 +450,12 @@ __device__ __forceinline__ double crt_dmod(double z, double P, double invP)  // 
     return r;
 }
 
-// thread = (group of 4 rows, column): the L words R[t][g][j] hold the residues of the 4 entries
+// Thread = (group of 4 rows, column): the L words R[t][g][j] hold the residues of its 4 entries, loaded two groups of
+// moduli ahead of their use.  Per group of three moduli: Garner inside the group gives the residue x_b modulo the
+// 24-bit super-modulus P_b; then the classical formula  value = sum_b y_b (M / P_b) - kappa M,  y_b = x_b (M / P_b)^-1
+// mod P_b:  the big products in 32-bit words, kappa = round(sum_b y_b / P_b) in fp64 -- exact because |value| / M < 1/4
+// (k_crt_decide) while the fraction sum is good to 1e-14.  The table entries of a group are wave-uniform scalars, read
+// once for the four entries.
 __global__ void __launch_bounds__(256) k_crt_finish(int row0, int row1, int n, const int *__restrict__ info,
                                                     const int *__restrict__ EA, const int *__restrict__ EB, double beta,
                                                     double *__restrict__ c, long long ldc, int round_mode,
@@ -409,96 +464,99 @@ __global__ void __launch_bounds__(256) k_crt_finish(int row0, int row1, int n, c
     if (info[INFO_PATH] != PATH_CRT) return;
     const int L = info[INFO_CRT_L], na = info[INFO_CRT_NA], nb = info[INFO_CRT_NB];
     const long long loc = (long long)blockIdx.x * 256 + threadIdx.x;
-    const int g0 = row0 >> 2, groups = (row1 - row0 + 3) >> 2;
+    const int groups = (row1 - row0 + 3) >> 2;
     if (loc >= (long long)groups * n) return;
-    const int g = g0 + (int)(loc / n), gj = (int)(loc % n);
-    unsigned res[CRT_LMAX];
+    const int g = (row0 >> 2) + (int)(loc / n), gj = (int)(loc % n);
+    const int G = (L + 2) / 3, wlast = L - 3 * (G - 1);   // groups in use; moduli in the last one (1..3)
+    const int nw = min(CRT_W32, ((g_crt.bits[L] + 32) >> 5) + 1);  // words of M_L, plus one for the sum of up to 13 terms
+    const size_t stride = (size_t)m4 * n;
+    const unsigned *rp = R + (size_t)g * n + gj;
+    auto fetch = [&](int b, unsigned (&d)[3]) {
 #pragma unroll
-    for (int t = 0; t < CRT_LMAX; ++t) res[t] = t < L ? R[((size_t)t * m4 + g) * n + gj] : 0u;
-    const int G = (L + 2) / 3, wlast = L - 3 * (G - 1);  // groups in use; moduli in the last one (1..3)
+        for (int j = 0; j < 3; ++j) d[j] = rp[(size_t)min(3 * b + j, L - 1) * stride];  // past the end: a valid word, unused
+    };
+    unsigned acc[4][CRT_W32];
+    double phi[4];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        phi[o] = 0.0;
+#pragma unroll
+        for (int i = 0; i < CRT_W32; ++i) acc[o][i] = 0u;
+    }
+    unsigned cur[3], nx1[3], nx2[3];
+    fetch(0, cur);
+    fetch(1, nx1);
+#pragma unroll 1
+    for (int b = 0; b < G; ++b) {
+        fetch(b + 2, nx2);
+        const int w = b == G - 1 ? wlast : 3;
+        const double p0 = g_crt.gp[b][0], p1 = g_crt.gp[b][1], p2 = g_crt.gp[b][2];
+        const double ip1 = g_crt.gip[b][1], ip2 = g_crt.gip[b][2];
+        const double i01 = g_crt.gi01[b], i02 = g_crt.gi02[b], i12 = g_crt.gi12[b], p01 = g_crt.P[b][1];
+        const double Pb = g_crt.P[b][w - 1], iPb = g_crt.invP[b][w - 1], wcb = g_crt.wc[L][b];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const double r0 = (double)((cur[0] >> (8 * o)) & 255u);
+            double x = r0;
+            if (w >= 2) {
+                const double r1 = (double)((cur[1] >> (8 * o)) & 255u);
+                const double v1 = crt_dmod((r1 - r0) * i01, p1, ip1);
+                x = fma(p0, v1, r0);
+                if (w >= 3) {
+                    const double r2 = (double)((cur[2] >> (8 * o)) & 255u);
+                    const double v2 = crt_dmod(((r2 - r0) * i02 - v1) * i12, p2, ip2);
+                    x = fma(p01, v2, x);
+                }
+            }
+            const double y = crt_dmod(x * wcb, Pb, iPb);
+            phi[o] = fma(y, iPb, phi[o]);
+            const unsigned yb = (unsigned)y;
+            unsigned long long carry = 0;
+#pragma unroll
+            for (int i = 0; i < CRT_W32; ++i) {
+                if (i < nw) {
+                    const unsigned long long t = (unsigned long long)g_crt.MP[L][b][i] * yb + acc[o][i] + carry;
+                    acc[o][i] = (unsigned)t;
+                    carry = t >> 32;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            cur[j] = nx1[j];
+            nx1[j] = nx2[j];
+        }
+    }
     const int ebj = EB[gj] - nb;
 #pragma unroll 1
     for (int o = 0; o < 4; ++o) {
         const int gi = 4 * g + o;
         if (gi >= row1) break;
-        // 1. inside each group: three 8-bit residues -> the residue modulo the group's 24-bit super-modulus
-        double X[CRT_G];
+        // minus kappa * M_L, over all words: a negative value comes out in two's complement
+        unsigned a10[CRT_W32];
+        double ph = phi[0];
 #pragma unroll
-        for (int b = 0; b < CRT_G; ++b) {
-            X[b] = 0.0;
-            if (b < G) {
-                const int w = b == G - 1 ? wlast : 3;
-                const double r0 = (double)((res[3 * b] >> (8 * o)) & 255u);
-                double x = r0;
-                if (w >= 2) {
-                    const double r1 = (double)((res[3 * b + 1] >> (8 * o)) & 255u);
-                    const double v1 = crt_dmod((r1 - r0) * g_crt.gi01[b], g_crt.gp[b][1], g_crt.gip[b][1]);
-                    x = fma(g_crt.gp[b][0], v1, r0);
-                    if (w >= 3) {
-                        const double r2 = (double)((res[3 * b + 2] >> (8 * o)) & 255u);
-                        const double v2 = crt_dmod(((r2 - r0) * g_crt.gi02[b] - v1) * g_crt.gi12[b], g_crt.gp[b][2],
-                                                   g_crt.gip[b][2]);
-                        x = fma(g_crt.P[b][1], v2, x);
-                    }
-                }
-                X[b] = x;
+        for (int i = 0; i < CRT_W32; ++i) a10[i] = acc[0][i];
+#pragma unroll
+        for (int q = 1; q < 4; ++q)
+            if (o == q) {
+                ph = phi[q];
+#pragma unroll
+                for (int i = 0; i < CRT_W32; ++i) a10[i] = acc[q][i];
             }
-        }
-        // 2. Garner across the groups: mixed-radix digits V_b, value = V_0 + P_0 (V_1 + P_1 (V_2 + ...))
+        const unsigned kappa = (unsigned)rint(ph);
+        unsigned long long mc = 0, borrow = 0;
 #pragma unroll
-        for (int b = 1; b < CRT_G; ++b) {
-            if (b < G) {
-                const int w = (b == G - 1 ? wlast : 3) - 1;
-                const double Pb = g_crt.P[b][w], iPb = g_crt.invP[b][w];
-                double t = X[b];
-#pragma unroll
-                for (int a = 0; a < b; ++a) t = crt_dmod((t - X[a]) * g_crt.ginv[a][b][w], Pb, iPb);
-                X[b] = t;
-            }
-        }
-        // 3. the integer: sum_b V_b * (P_0 ... P_{b-1}) in 32-bit words
-        unsigned acc[CRT_W32];
-#pragma unroll
-        for (int i = 0; i < CRT_W32; ++i) acc[i] = 0u;
-#pragma unroll
-        for (int b = 0; b < CRT_G; ++b) {
-            if (b < G) {
-                constexpr int dummy = 0;
-                (void)dummy;
-                const unsigned vb = (unsigned)X[b];
-                unsigned long long carry = 0;
-#pragma unroll
-                for (int i = 0; i < CRT_W32; ++i) {
-                    // Q_b < 2^(24 b): words above that are zero, the running sum stays below 2^(24 (b + 1))
-                    if (32 * i < 24 * (b + 1) + 32) {
-                        const unsigned long long t = (unsigned long long)g_crt.Q[b][i] * vb + acc[i] + carry;
-                        acc[i] = (unsigned)t;
-                        carry = t >> 32;
-                    }
-                }
-            }
-        }
-        // 4. sign: values >= floor(M/2) + 1 stand for value - M
-        {
-            unsigned long long borrow = 0;
-#pragma unroll
-            for (int i = 0; i < CRT_W32; ++i) {
-                const unsigned long long d = (unsigned long long)acc[i] - g_crt.H[L][i] - borrow;
-                borrow = (d >> 32) & 1ull;
-            }
-            if (!borrow) {
-                unsigned long long bw = 0;
-#pragma unroll
-                for (int i = 0; i < CRT_W32; ++i) {
-                    const unsigned long long d = (unsigned long long)acc[i] - g_crt.M[L][i] - bw;
-                    acc[i] = (unsigned)d;
-                    bw = (d >> 32) & 1ull;
-                }
-            }
+        for (int i = 0; i < CRT_W32; ++i) {
+            const unsigned long long prod = (unsigned long long)g_crt.M[L][i] * kappa + mc;
+            mc = prod >> 32;
+            const unsigned long long d = (unsigned long long)a10[i] - (prod & 0xffffffffull) - borrow;
+            a10[i] = (unsigned)d;
+            borrow = (d >> 32) & 1ull;
         }
         unsigned long long w5[CRT_W32 / 2];
 #pragma unroll
-        for (int i = 0; i < CRT_W32 / 2; ++i) w5[i] = (unsigned long long)acc[2 * i] | ((unsigned long long)acc[2 * i + 1] << 32);
+        for (int i = 0; i < CRT_W32 / 2; ++i) w5[i] = (unsigned long long)a10[2 * i] | ((unsigned long long)a10[2 * i + 1] << 32);
         const int u0 = EA[gi] - na + ebj;
         const double s = round_mode ? wide_round_reference<CRT_W32 / 2>(w5, u0) : wide_round_n<CRT_W32 / 2>(w5, u0);
         double *cij = c + (long long)gi * ldc + gj;
@@ -579,6 +637,7 @@ hipError_t exgemm_crt_prepare(Ctx &c, char transa, char transb, int m, int n, in
     plan->info = info; plan->EA = EA; plan->EB = EB; plan->PA = PA; plan->PB = PB;
     plan->R = (unsigned *)(base + o_r);
     plan->plane_a = plane_a; plan->plane_b = plane_b; plan->lcap = lcap; plan->m4 = m4;
+    plan->dbg = (c.variant >= 11 && c.variant <= 15) ? c.variant - 10 : 0;  // timing experiments only (wrong results)
     plan->beta = beta; plan->c = cmat; plan->ldc = ldc; plan->round_mode = round_mode;
     c.gemm_info_dev = info;
     return hipGetLastError();
@@ -591,10 +650,17 @@ hipError_t exgemm_crt_rows(const I8Plan &p, int row0, int row1, hipStream_t st)
     const int gy = (p.m + I8_T - 1) / I8_T, gx = (p.n + I8_T - 1) / I8_T;
     const int ty0 = row0 / I8_T, ty_cnt = (row1 - row0 + I8_T - 1) / I8_T;
     const int by_cnt = (ty_cnt + 3) / 4, bx_cnt = (gx + 3) / 4;
-    for (int kc0 = 0; kc0 < p.KC; kc0 += CRT_KPASS)
-        hipLaunchKernelGGL(k_gemm_crt, dim3((unsigned)(p.lcap * by_cnt * bx_cnt)), dim3(256), 0, st, p.n, row1, ty0, ty_cnt,
-                           gy, gx, p.KC, kc0, min(p.KC, kc0 + CRT_KPASS), p.PA, p.PB, p.plane_a, p.plane_b, p.info, p.R,
-                           p.m4);
+    for (int kc0 = 0; kc0 < p.KC; kc0 += CRT_KPASS) {
+#define CRT_LAUNCH(D)                                                                                                    \
+    hipLaunchKernelGGL((k_gemm_crt<D>), dim3((unsigned)(p.lcap * by_cnt * bx_cnt)), dim3(256), 0, st, p.n, row1, ty0,      \
+                       ty_cnt, gy, gx, p.KC, kc0, min(p.KC, kc0 + CRT_KPASS), p.PA, p.PB, p.plane_a, p.plane_b, p.info,  \
+                       p.R, p.m4, p.dbg)
+        if (p.dbg == 3) CRT_LAUNCH(3);
+        else if (p.dbg == 4) CRT_LAUNCH(4);
+        else if (p.dbg == 5) CRT_LAUNCH(5);
+        else CRT_LAUNCH(0);
+#undef CRT_LAUNCH
+    }
     const long long groups = (row1 - row0 + 3) / 4;
     hipLaunchKernelGGL(k_crt_finish, dim3((unsigned)((groups * p.n + 255) / 256)), dim3(256), 0, st, row0, row1, p.n, p.info,
                        p.EA, p.EB, p.beta, p.c, (long long)p.ldc, p.round_mode, p.R, p.m4);
