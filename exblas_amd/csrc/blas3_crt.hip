@@ -81,24 +81,6 @@ struct Big {  // little-endian 32-bit words
             carry = t >> 32;
         }
     }
-    void add_small(uint32_t v)
-    {
-        uint64_t carry = v;
-        for (auto &x : w) {
-            const uint64_t t = (uint64_t)x + carry;
-            x = (uint32_t)t;
-            carry = t >> 32;
-        }
-    }
-    void half()
-    {
-        uint32_t carry = 0;
-        for (int i = CRT_W32 + 1; i >= 0; --i) {
-            const uint32_t nc = w[i] & 1u;
-            w[i] = (w[i] >> 1) | (carry << 31);
-            carry = nc;
-        }
-    }
     uint32_t div_small(uint32_t d)  // in place; returns the remainder
     {
         uint64_t rem = 0;
@@ -279,12 +261,11 @@ __global__ void __launch_bounds__(256) k_crt_residues(const double *__restrict__
 // and issues 2 x 16 MFMAs; the fragments of the next k-step and one staging instruction are issued between the MFMAs
 // of the current k-step, one barrier per chunk.
 // Result: R[modulus][row / 4][col] = the four residues (rows 4g .. 4g+3, unsigned bytes) of C mod p_t.
-template <int DBG>
 __global__ void __launch_bounds__(256, 1) k_gemm_crt(int n, int row_end, int ty0, int ty_cnt, int gy, int gx, int KC,
                                                      int kc0, int kc1, const signed char *__restrict__ PA,
                                                      const signed char *__restrict__ PB,
                                                      size_t plane_a, size_t plane_b, const int *__restrict__ info,
-                                                     unsigned *__restrict__ R, int m4, int dbg)
+                                                     unsigned *__restrict__ R, int m4)
 {
     __shared__ v4i_t lds[3][8 * 256];
     if (info[INFO_PATH] != PATH_CRT) return;
@@ -294,10 +275,6 @@ __global__ void __launch_bounds__(256, 1) k_gemm_crt(int n, int row_end, int ty0
     if (mod >= L) return;
     int by, bx;
     tile_of_block(blockIdx.x - mod * ntiles, ntiles, by_cnt, bx_cnt, &by, &bx);
-    if (dbg == 2) {
-        by = (blockIdx.x - mod * ntiles) / bx_cnt;
-        bx = (blockIdx.x - mod * ntiles) % bx_cnt;
-    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wy = wave >> 1, wx = wave & 1, half = lane >> 5;
     const int p = g_crt.p[mod];
     const float invp = g_crt.invp[mod];
@@ -321,11 +298,11 @@ __global__ void __launch_bounds__(256, 1) k_gemm_crt(int n, int row_end, int ty0
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[g][r] = 0;
 
-    auto clampk = [&](int kc) { return dbg == 1 ? kc0 : (kc < kc1 ? kc : kc1 - 1); };
-    // Staging through registers: global_load_dwordx4 -> (two chunks later) ds_write_b128.  An LDS-DMA piece costs the
-    // issuing wave 100-185 cycles beside this many fragment reads (MI355X_MICROARCH.md, 'LDS-DMA piece issue cost'),
-    // and a chunk of 2 x 16 MFMAs needs 8 pieces per wave every ~1000 cycles: with DMA staging the matrix pipe was
-    // 55-58 % busy.  Chunk c lives in LDS stage c % 3 and, before that, in register set c % 3; in iteration i (chunk
+    auto clampk = [&](int kc) { return kc < kc1 ? kc : kc1 - 1; };
+    // Staging through registers: global_load_dwordx4 -> (two chunks later) ds_write_b128.  Measured at 8192^3, 18 moduli:
+    // this form 9.2 ms; LDS-DMA with two stages 9.7, with four 9.1; the same loop without any staging (stale LDS) 7.2 and
+    // with neither fragment reads nor barriers 7.05 -- the chip is power-limited here (the clock drops as the matrix
+    // pipe fills), so what staging costs is its energy, not its issue slots or its latency.  Chunk c lives in LDS stage c % 3 and, before that, in register set c % 3; in iteration i (chunk
     // i): MFMAs of chunk i, fragment reads for the next k-step, ds_write of chunk i + 2 (set -> stage (i + 2) % 3, free
     // since the barrier of iteration i - 1), global loads of chunk i + 4 into the set chunk i + 1 left.  One barrier
     // per chunk, LDS traffic only (no vmcnt wait: the loads in flight belong to later chunks).
@@ -355,16 +332,10 @@ __global__ void __launch_bounds__(256, 1) k_gemm_crt(int n, int row_end, int ty0
         constexpr int wset = (r + 2) % 3, lset = (r + 1) % 3;
         static_for_i8<0, 8>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
-            if constexpr (DBG < 5) {
-                if constexpr (i < 4) nb[i] = lds[rstage][bbase + (i >> 1) * 256 + (i & 1) * 128 + fo[rks]];
-                else na[i - 4] = lds[rstage][abase + ((i - 4) >> 1) * 256 + ((i - 4) & 1) * 128 + fo[rks]];
-            } else {
-                if constexpr (i < 4) nb[i] = cb[i]; else na[i - 4] = ca[i - 4];
-            }
-            if constexpr (DBG < 3) {
-                if constexpr (i & 1) lwrite(std::integral_constant<int, wset>{}, std::integral_constant<int, h * 4 + i / 2>{});
-                else gload(std::integral_constant<int, lset>{}, std::integral_constant<int, h * 4 + i / 2>{}, kc + 4);
-            }
+            if constexpr (i < 4) nb[i] = lds[rstage][bbase + (i >> 1) * 256 + (i & 1) * 128 + fo[rks]];
+            else na[i - 4] = lds[rstage][abase + ((i - 4) >> 1) * 256 + ((i - 4) & 1) * 128 + fo[rks]];
+            if constexpr (i & 1) lwrite(std::integral_constant<int, wset>{}, std::integral_constant<int, h * 4 + i / 2>{});
+            else gload(std::integral_constant<int, lset>{}, std::integral_constant<int, h * 4 + i / 2>{}, kc + 4);
             static_for_i8<2 * i, 2 * i + 2>([&](auto mc) {
                 constexpr int mm = decltype(mc)::value, pu = mm >> 2, qu = mm & 3;
                 acc[mm] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ca[pu], cb[qu], acc[mm], 0, 0, 0);
@@ -378,7 +349,7 @@ __global__ void __launch_bounds__(256, 1) k_gemm_crt(int n, int row_end, int ty0
         khalf(std::integral_constant<int, 0>{}, rc, fa0, fb0, fa1, fb1, kc);
         // the stores of chunk kc+1 (previous iteration) and the first half of chunk kc+2 are visible after this; nobody
         // reads stage r any more
-        if constexpr (DBG < 4) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         khalf(std::integral_constant<int, 1>{}, rc, fa1, fb1, fa0, fb0, kc);
     };
     // prologue: chunks 0 and 1 through registers into stages 0 and 1, chunks 2 and 3 into sets 2 and 0
@@ -456,53 +427,44 @@ __device__ __forceinline__ double crt_dmod(double z, double P, double invP)  // 
 // mod P_b:  the big products in 32-bit words, kappa = round(sum_b y_b / P_b) in fp64 -- exact because |value| / M < 1/4
 // (k_crt_decide) while the fraction sum is good to 1e-14.  The table entries of a group are wave-uniform scalars, read
 // once for the four entries.
-__global__ void __launch_bounds__(256) k_crt_finish(int row0, int row1, int n, const int *__restrict__ info,
-                                                    const int *__restrict__ EA, const int *__restrict__ EB, double beta,
-                                                    double *__restrict__ c, long long ldc, int round_mode,
-                                                    const unsigned *__restrict__ R, int m4)
+// NW = 32-bit words the sums are carried in (a bucket of the width of M_L): the inner loops carry no branches
+template <int NW>
+__device__ __forceinline__ void crt_finish_body(int L, int na, int nb, int g, int gj, int row1, const unsigned *__restrict__ rp,
+                                                size_t stride, const int *__restrict__ EA, const int *__restrict__ EB,
+                                                double beta, double *__restrict__ c, long long ldc, int round_mode)
 {
-    if (info[INFO_PATH] != PATH_CRT) return;
-    const int L = info[INFO_CRT_L], na = info[INFO_CRT_NA], nb = info[INFO_CRT_NB];
-    const long long loc = (long long)blockIdx.x * 256 + threadIdx.x;
-    const int groups = (row1 - row0 + 3) >> 2;
-    if (loc >= (long long)groups * n) return;
-    const int g = (row0 >> 2) + (int)(loc / n), gj = (int)(loc % n);
     const int G = (L + 2) / 3, wlast = L - 3 * (G - 1);   // groups in use; moduli in the last one (1..3)
-    const int nw = min(CRT_W32, ((g_crt.bits[L] + 32) >> 5) + 1);  // words of M_L, plus one for the sum of up to 13 terms
-    const size_t stride = (size_t)m4 * n;
-    const unsigned *rp = R + (size_t)g * n + gj;
     auto fetch = [&](int b, unsigned (&d)[3]) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) d[j] = rp[(size_t)min(3 * b + j, L - 1) * stride];  // past the end: a valid word, unused
     };
-    unsigned acc[4][CRT_W32];
+    unsigned acc[4][NW];
     double phi[4];
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
         phi[o] = 0.0;
 #pragma unroll
-        for (int i = 0; i < CRT_W32; ++i) acc[o][i] = 0u;
+        for (int i = 0; i < NW; ++i) acc[o][i] = 0u;
     }
-    unsigned cur[3], nx1[3], nx2[3];
-    fetch(0, cur);
-    fetch(1, nx1);
-#pragma unroll 1
-    for (int b = 0; b < G; ++b) {
-        fetch(b + 2, nx2);
-        const int w = b == G - 1 ? wlast : 3;
+    // one group of moduli for the four entries; W = 3: a full group (no branches), W = 0: w moduli, known at run time
+    auto group = [&](auto wc_, int b, int w, const unsigned (&cur)[3]) {
+        constexpr int W = decltype(wc_)::value;
         const double p0 = g_crt.gp[b][0], p1 = g_crt.gp[b][1], p2 = g_crt.gp[b][2];
         const double ip1 = g_crt.gip[b][1], ip2 = g_crt.gip[b][2];
         const double i01 = g_crt.gi01[b], i02 = g_crt.gi02[b], i12 = g_crt.gi12[b], p01 = g_crt.P[b][1];
         const double Pb = g_crt.P[b][w - 1], iPb = g_crt.invP[b][w - 1], wcb = g_crt.wc[L][b];
+        unsigned mp[NW];
+#pragma unroll
+        for (int i = 0; i < NW; ++i) mp[i] = g_crt.MP[L][b][i];
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
             const double r0 = (double)((cur[0] >> (8 * o)) & 255u);
             double x = r0;
-            if (w >= 2) {
+            if (W == 3 || w >= 2) {
                 const double r1 = (double)((cur[1] >> (8 * o)) & 255u);
                 const double v1 = crt_dmod((r1 - r0) * i01, p1, ip1);
                 x = fma(p0, v1, r0);
-                if (w >= 3) {
+                if (W == 3 || w >= 3) {
                     const double r2 = (double)((cur[2] >> (8 * o)) & 255u);
                     const double v2 = crt_dmod(((r2 - r0) * i02 - v1) * i12, p2, ip2);
                     x = fma(p01, v2, x);
@@ -513,37 +475,44 @@ __global__ void __launch_bounds__(256) k_crt_finish(int row0, int row1, int n, c
             const unsigned yb = (unsigned)y;
             unsigned long long carry = 0;
 #pragma unroll
-            for (int i = 0; i < CRT_W32; ++i) {
-                if (i < nw) {
-                    const unsigned long long t = (unsigned long long)g_crt.MP[L][b][i] * yb + acc[o][i] + carry;
-                    acc[o][i] = (unsigned)t;
-                    carry = t >> 32;
-                }
+            for (int i = 0; i < NW; ++i) {
+                const unsigned long long t = (unsigned long long)mp[i] * yb + acc[o][i] + carry;
+                acc[o][i] = (unsigned)t;
+                carry = t >> 32;
             }
         }
+    };
+    unsigned cur[3], nx1[3], nx2[3];
+    fetch(0, cur);
+    fetch(1, nx1);
+#pragma unroll 1
+    for (int b = 0; b < G - 1; ++b) {
+        fetch(b + 2, nx2);
+        group(std::integral_constant<int, 3>{}, b, 3, cur);
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             cur[j] = nx1[j];
             nx1[j] = nx2[j];
         }
     }
+    group(std::integral_constant<int, 0>{}, G - 1, wlast, cur);
     const int ebj = EB[gj] - nb;
 #pragma unroll 1
     for (int o = 0; o < 4; ++o) {
         const int gi = 4 * g + o;
         if (gi >= row1) break;
-        // minus kappa * M_L, over all words: a negative value comes out in two's complement
         unsigned a10[CRT_W32];
         double ph = phi[0];
 #pragma unroll
-        for (int i = 0; i < CRT_W32; ++i) a10[i] = acc[0][i];
+        for (int i = 0; i < CRT_W32; ++i) a10[i] = i < NW ? acc[0][i] : 0u;
 #pragma unroll
         for (int q = 1; q < 4; ++q)
             if (o == q) {
                 ph = phi[q];
 #pragma unroll
-                for (int i = 0; i < CRT_W32; ++i) a10[i] = acc[q][i];
+                for (int i = 0; i < NW; ++i) a10[i] = acc[q][i];
             }
+        // minus kappa * M_L, over all words: a negative value comes out in two's complement
         const unsigned kappa = (unsigned)rint(ph);
         unsigned long long mc = 0, borrow = 0;
 #pragma unroll
@@ -562,6 +531,27 @@ __global__ void __launch_bounds__(256) k_crt_finish(int row0, int row1, int n, c
         double *cij = c + (long long)gi * ldc + gj;
         *cij = (beta == 0.0) ? s : beta * (*cij) + s;
     }
+}
+
+// one kernel per bucket (its own register budget); the launches of the other buckets exit at once
+template <int NW, int NWPREV>
+__global__ void __launch_bounds__(256) k_crt_finish(int row0, int row1, int n, const int *__restrict__ info,
+                                                    const int *__restrict__ EA, const int *__restrict__ EB, double beta,
+                                                    double *__restrict__ c, long long ldc, int round_mode,
+                                                    const unsigned *__restrict__ R, int m4)
+{
+    if (info[INFO_PATH] != PATH_CRT) return;
+    const int L = info[INFO_CRT_L], na = info[INFO_CRT_NA], nb = info[INFO_CRT_NB];
+    // words of M_L, plus one for the sum of up to 13 terms below M_L each
+    const int nw = ((g_crt.bits[L] + 32) >> 5) + 1;
+    if (nw > NW || nw <= NWPREV) return;
+    const long long loc = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int groups = (row1 - row0 + 3) >> 2;
+    if (loc >= (long long)groups * n) return;
+    const int g = (row0 >> 2) + (int)(loc / n), gj = (int)(loc % n);
+    const size_t stride = (size_t)m4 * n;
+    const unsigned *rp = R + (size_t)g * n + gj;
+    crt_finish_body<NW>(L, na, nb, g, gj, row1, rp, stride, EA, EB, beta, c, ldc, round_mode);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -637,7 +627,6 @@ hipError_t exgemm_crt_prepare(Ctx &c, char transa, char transb, int m, int n, in
     plan->info = info; plan->EA = EA; plan->EB = EB; plan->PA = PA; plan->PB = PB;
     plan->R = (unsigned *)(base + o_r);
     plan->plane_a = plane_a; plan->plane_b = plane_b; plan->lcap = lcap; plan->m4 = m4;
-    plan->dbg = (c.variant >= 11 && c.variant <= 15) ? c.variant - 10 : 0;  // timing experiments only (wrong results)
     plan->beta = beta; plan->c = cmat; plan->ldc = ldc; plan->round_mode = round_mode;
     c.gemm_info_dev = info;
     return hipGetLastError();
@@ -650,20 +639,19 @@ hipError_t exgemm_crt_rows(const I8Plan &p, int row0, int row1, hipStream_t st)
     const int gy = (p.m + I8_T - 1) / I8_T, gx = (p.n + I8_T - 1) / I8_T;
     const int ty0 = row0 / I8_T, ty_cnt = (row1 - row0 + I8_T - 1) / I8_T;
     const int by_cnt = (ty_cnt + 3) / 4, bx_cnt = (gx + 3) / 4;
-    for (int kc0 = 0; kc0 < p.KC; kc0 += CRT_KPASS) {
-#define CRT_LAUNCH(D)                                                                                                    \
-    hipLaunchKernelGGL((k_gemm_crt<D>), dim3((unsigned)(p.lcap * by_cnt * bx_cnt)), dim3(256), 0, st, p.n, row1, ty0,      \
-                       ty_cnt, gy, gx, p.KC, kc0, min(p.KC, kc0 + CRT_KPASS), p.PA, p.PB, p.plane_a, p.plane_b, p.info,  \
-                       p.R, p.m4, p.dbg)
-        if (p.dbg == 3) CRT_LAUNCH(3);
-        else if (p.dbg == 4) CRT_LAUNCH(4);
-        else if (p.dbg == 5) CRT_LAUNCH(5);
-        else CRT_LAUNCH(0);
-#undef CRT_LAUNCH
-    }
+    for (int kc0 = 0; kc0 < p.KC; kc0 += CRT_KPASS)
+        hipLaunchKernelGGL(k_gemm_crt, dim3((unsigned)(p.lcap * by_cnt * bx_cnt)), dim3(256), 0, st, p.n, row1, ty0, ty_cnt,
+                           gy, gx, p.KC, kc0, min(p.KC, kc0 + CRT_KPASS), p.PA, p.PB, p.plane_a, p.plane_b, p.info, p.R,
+                           p.m4);
     const long long groups = (row1 - row0 + 3) / 4;
-    hipLaunchKernelGGL(k_crt_finish, dim3((unsigned)((groups * p.n + 255) / 256)), dim3(256), 0, st, row0, row1, p.n, p.info,
-                       p.EA, p.EB, p.beta, p.c, (long long)p.ldc, p.round_mode, p.R, p.m4);
+#define CRT_FIN(NW, NWPREV)                                                                                              \
+    hipLaunchKernelGGL((k_crt_finish<NW, NWPREV>), dim3((unsigned)((groups * p.n + 255) / 256)), dim3(256), 0, st, row0,  \
+                       row1, p.n, p.info, p.EA, p.EB, p.beta, p.c, (long long)p.ldc, p.round_mode, p.R, p.m4)
+    CRT_FIN(4, 0);
+    CRT_FIN(6, 4);
+    CRT_FIN(8, 6);
+    CRT_FIN(CRT_W32, 8);
+#undef CRT_FIN
     return hipGetLastError();
 }
 

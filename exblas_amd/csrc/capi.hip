@@ -404,6 +404,15 @@ void exblas_set_gemm_max_slices(int s)
     });
 }
 
+void exblas_set_gemm_max_moduli(int l)
+{
+    ctx(-1);
+    for_each_layer(current_device(), [&](Ctx &c) {
+        std::lock_guard<std::mutex> lk(c.mu);
+        c.gemm_max_moduli = l;
+    });
+}
+
 void exblas_set_gemm_path(int mode)
 {
     ctx(-1);

@@ -73,17 +73,25 @@ const char *exblas_hip_version(void);
 /* Launch-geometry knobs for A/B measurements (<= 0 / < 0 leave a value unchanged): resident blocks per CU
  * of the streaming kernels, number of global group accumulators, kernel variant (0 = production). */
 int exblas_set_tuning(int blocks_per_cu, int ngroups, int variant);
-/* ExGEMM implementation.  0 (default; 2 is a synonym): error-free 8-bit slices on the int8 matrix cores
+/* ExGEMM implementation.  0 (default): error-free integer arithmetic on the int8 matrix cores
  * (v_mfma_i32_32x32x32_i8) for every (fpe, early_exit) variant and both rounding modes whenever the data qualifies --
- * decided on the device, the scalar kernel runs otherwise; 1 = scalar kernel only (TwoProd + expansions + one
- * superaccumulator per output, the reference's own scheme); 3 = error-free 21-bit slices on MFMA-F64
- * (v_mfma_f64_16x16x4_f64; host-decided: synchronises the stream, exact-rounding mode only).  Same bits on every path. */
+ * decided on the device, the scalar kernel runs otherwise.  Products with min(m, n) >= 192 use residues modulo
+ * pairwise coprime 8-bit moduli (one int8 GEMM per modulus, Chinese-remainder reconstruction: blas3_crt.hip), smaller
+ * ones base-256 digit slices (all digit pairs: blas3_i8.hip); 4 = residues always, 2 = digit slices always;
+ * 1 = scalar kernel only (TwoProd + expansions + one superaccumulator per output, the reference's own scheme);
+ * 3 = error-free 21-bit slices on MFMA-F64 (v_mfma_f64_16x16x4_f64; host-decided: synchronises the stream,
+ * exact-rounding mode only).  Same bits on every path. */
 void exblas_set_gemm_path(int mode);
-/* digits per operand the int8 path may use (workspace: that many bytes per matrix entry); 0 = default 16 */
+/* digits per operand the digit-slice path may use (workspace: that many bytes per matrix entry); 0 = default 16 */
 void exblas_set_gemm_max_slices(int s);
-/* Which implementation the last exgemm on this device used: out[0] = 0 scalar kernel / 1 fp64 slices / 2 int8
- * slices, out[1], out[2] = slices of A, B (out[1]*out[2] matrix multiply-adds per element pair).  Synchronises the
- * device when the decision was taken there.  exblas_last_gemm_slices() = max(out[1], out[2]), 0 for the scalar kernel. */
+/* moduli the residue path may use (workspace: that many bytes per entry of A, B and 4-row group of C);
+ * 0 = default 39 = every input the path accepts (126 bits per operand) */
+void exblas_set_gemm_max_moduli(int l);
+/* Which implementation the last exgemm on this device used: out[0] = 0 scalar kernel / 1 fp64 slices / 2 int8 digit
+ * slices / 4 int8 residues.  Slices: out[1], out[2] = slices of A, B (out[1]*out[2] matrix multiply-adds per element
+ * pair).  Residues: out[1], out[2] = bits of the fixed-point entries of A, B; out[3] = moduli (= matrix multiply-adds
+ * per element pair).  Synchronises the device when the decision was taken there.  exblas_last_gemm_slices() =
+ * max(out[1], out[2]) for the slice paths, out[3] for residues, 0 for the scalar kernel. */
 int exblas_last_gemm_info(int *out8);
 int exblas_last_gemm_slices(void);
 /* Makes the *_dev layer's workspace at least `bytes` large (see "Workspace and hipGraphs" above). */

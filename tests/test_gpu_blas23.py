@@ -102,11 +102,117 @@ def test_exgemm_trans_alpha_beta(ex, oracle):
 
 
 def gemm_info(lib):
-    """(path, slices of A, slices of B) of the last exgemm: path 0 scalar kernel, 1 fp64 slices, 2 int8 slices"""
+    """(path, slices of A, slices of B) of the last exgemm: path 0 scalar kernel, 1 fp64 slices, 2 int8 digit slices;
+    4 int8 residues: (4, bits of A, bits of B, moduli)"""
     import ctypes as C
     v = (C.c_int * 8)()
     assert lib.exblas_last_gemm_info(v) == 0
-    return v[0], v[1], v[2]
+    return (v[0], v[1], v[2], v[3]) if v[0] == 4 else (v[0], v[1], v[2])
+
+
+# cumulative bits of the residue path's moduli 256, 255, 253, 251, 247, 241, ... (floor(log2(product of the first L)))
+def _crt_moduli_needed(bits_a, bits_b, k):
+    from math import gcd
+    need = bits_a + bits_b + max(0, (k - 1).bit_length()) + 2
+    ps, prod, c = [], 1, 256
+    while prod.bit_length() - 1 < need:
+        if all(gcd(c, q) == 1 for q in ps):
+            ps.append(c)
+            prod *= c
+        c -= 1
+    return len(ps)
+
+
+@pytest.mark.parametrize("m,n,k", [(64, 64, 512), (130, 75, 1100), (16, 200, 33), (200, 260, 150), (257, 300, 70)])
+def test_exgemm_residue_path_is_exact(ex, oracle, m, n, k):
+    """The residue path (blas3_crt.hip: one int8 GEMM per 8-bit modulus + Chinese-remainder reconstruction), forced
+    (mode 4) on shapes below its automatic threshold and automatic (mode 0) from min(m, n) >= 192: the oracle's bits
+    for every data family, both rounding modes, transposes, leading dimensions, alpha / beta -- with exactly the number
+    of moduli the operand widths call for."""
+    lib = ex.load_library()
+    rng = np.random.default_rng(6)
+    cases = {
+        "fpuniform_r10": (oracle.gen("fpuniform", m * k, 81, 10, 0), oracle.gen("fpuniform", k * n, 82, 10, 0)),
+        "fpuniform_r17": (oracle.gen("fpuniform", m * k, 91, 17, 0), oracle.gen("fpuniform", k * n, 92, 17, 0)),
+        "naive": (oracle.gen("naive", m * k, 1), oracle.gen("naive", k * n, 1)),
+        "small_ints": (rng.integers(-1000, 1000, m * k).astype(np.float64), rng.integers(-1000, 1000, k * n).astype(np.float64)),
+        "ill_cond_1e32": (oracle.gen("ill_cond", m * k, 83, 1e32), oracle.gen("ill_cond", k * n, 84, 1e32)),
+        "wide_r60": (oracle.gen("fpuniform_signed", m * k, 85, 60, 30), oracle.gen("fpuniform_signed", k * n, 86, 60, 30)),
+        "ones": (np.ones(m * k), -np.ones(k * n)),
+    }
+    auto = min(m, n) >= 192
+    try:
+        for name, (a, b) in cases.items():
+            c0 = oracle.gen("fpuniform_signed", m * n, 87, 10, 5)
+            for mode in (oracle.ROUND_EXACT, oracle.ROUND_REFERENCE):
+                want = oracle.exgemm("N", "N", m, n, k, 1.0, a, k, b, n, 1.0, c0, n, 0, mode=mode)
+                lib.exblas_set_round_mode(mode)
+                for path in ((0, 4) if auto else (4,)):
+                    lib.exblas_set_gemm_path(path)
+                    c = c0.copy()
+                    ex.exgemm("N", "N", m, n, k, 1.0, a, k, b, n, 1.0, c, n, 8, True)
+                    info = gemm_info(lib)
+                    assert info[0] == 4, (name, path, info)
+                    assert info[3] == _crt_moduli_needed(info[1], info[2], k), (name, info)
+                    assert (_bits(c) == _bits(want)).all(), (name, path, mode, info, int((c != want).sum()))
+        lib.exblas_set_gemm_path(4)
+        for ta, tb in (("N", "T"), ("T", "N"), ("T", "T")):
+            lda = (m if ta == "T" else k) + 1
+            ldb = (k if tb == "T" else n) + 2
+            a = oracle.gen("fpuniform_signed", (k if ta == "T" else m) * lda, 91, 8, 4)
+            b = oracle.gen("fpuniform_signed", (n if tb == "T" else k) * ldb, 92, 8, 4)
+            c0 = oracle.gen("fpuniform_signed", m * (n + 3), 93, 8, 4)
+            for alpha, beta in ((1.0, 1.0), (0.5, 0.0), (-1.25, 2.0)):
+                for mode in (oracle.ROUND_EXACT, oracle.ROUND_REFERENCE):
+                    want = oracle.exgemm(ta, tb, m, n, k, alpha, a, lda, b, ldb, beta, c0, n + 3, 4, False, mode=mode)
+                    lib.exblas_set_round_mode(mode)
+                    c = c0.copy()
+                    ex.exgemm(ta, tb, m, n, k, alpha, a, lda, b, ldb, beta, c, n + 3, 4, False)
+                    assert gemm_info(lib)[0] == 4
+                    assert (_bits(c) == _bits(want)).all(), (ta, tb, alpha, beta, mode)
+    finally:
+        lib.exblas_set_gemm_path(0)
+        lib.exblas_set_round_mode(0)
+
+
+def test_exgemm_residue_path_long_k_and_capacity(ex, oracle):
+    """k > 8192 (one contraction launch per 8192, residues added modulo p), k = 1, and the capacity knob: with fewer
+    moduli reserved than the data needs the scalar kernel does the work -- same bits."""
+    lib = ex.load_library()
+    try:
+        lib.exblas_set_gemm_path(4)
+        for (m, n, k, kind, p0, p1) in ((33, 65, 9000, "fpuniform_signed", 10, 0), (70, 40, 16500, "ill_cond", 1e16, 0.0),
+                                        (50, 60, 1, "fpuniform", 10, 0), (260, 200, 8193, "fpuniform", 3, 0)):
+            a = oracle.gen(kind, m * k, 31, p0, p1)
+            b = oracle.gen(kind, k * n, 32, p0, p1)
+            c0 = oracle.gen("fpuniform_signed", m * n, 33, 10, 5)
+            for mode in (oracle.ROUND_EXACT, oracle.ROUND_REFERENCE):
+                want = oracle.exgemm("N", "N", m, n, k, 1.0, a, k, b, n, 1.0, c0, n, 0, mode=mode)
+                lib.exblas_set_round_mode(mode)
+                c = c0.copy()
+                ex.exgemm("N", "N", m, n, k, 1.0, a, k, b, n, 1.0, c, n, 8, True)
+                info = gemm_info(lib)
+                assert info[0] == 4, info
+                assert (_bits(c) == _bits(want)).all(), (m, n, k, kind, mode, info, int((c != want).sum()))
+        lib.exblas_set_round_mode(0)
+        lib.exblas_set_gemm_max_moduli(12)
+        m, n, k = 48, 48, 200
+        a, b = oracle.gen("ill_cond", m * k, 41, 1e32), oracle.gen("ill_cond", k * n, 42, 1e32)
+        want = oracle.exgemm("N", "N", m, n, k, 1.0, a, k, b, n, 0.0, np.zeros(m * n), n, 0)
+        c = np.zeros(m * n)
+        ex.exgemm("N", "N", m, n, k, 1.0, a, k, b, n, 0.0, c, n, 8, True)
+        assert gemm_info(lib)[0] == 0 and (_bits(c) == _bits(want)).all()
+        a, b = oracle.gen("naive", m * k, 43), oracle.gen("naive", k * n, 44)      # 53 + 53 + 8 + 2 bits: 15 moduli
+        want = oracle.exgemm("N", "N", m, n, k, 1.0, a, k, b, n, 0.0, np.zeros(m * n), n, 0)
+        ex.exgemm("N", "N", m, n, k, 1.0, a, k, b, n, 0.0, c, n, 8, True)
+        assert gemm_info(lib)[0] == 0 and (_bits(c) == _bits(want)).all()
+        lib.exblas_set_gemm_max_moduli(16)
+        ex.exgemm("N", "N", m, n, k, 1.0, a, k, b, n, 0.0, c, n, 8, True)
+        assert gemm_info(lib)[0] == 4 and (_bits(c) == _bits(want)).all()
+    finally:
+        lib.exblas_set_gemm_max_moduli(0)
+        lib.exblas_set_gemm_path(0)
+        lib.exblas_set_round_mode(0)
 
 
 @pytest.mark.parametrize("m,n,k", [(64, 64, 512), (130, 75, 1100), (16, 200, 33)])
@@ -221,6 +327,27 @@ def test_exgemm_is_stream_ordered_and_capturable(ex, oracle):
         want = oracle.exgemm("N", "N", m, n, k, 1.0, A.cpu().numpy(), k, B.cpu().numpy(), n, 0.0, np.zeros(m * n), n, 0)
         assert (_bits(C.cpu().numpy()) == _bits(want)).all(), kind
     assert gemm_info(lib)[0] == 0                # the last data set (log-normal, sigma 40) took the scalar kernel
+    # the same through the residue path (shapes from 192 x 192 up take it by default)
+    m2, n2, k2 = 256, 200, 320
+    A2 = ex.gen_dev("fpuniform", m2 * k2, 51, 10, 0)
+    B2 = ex.gen_dev("fpuniform", k2 * n2, 52, 10, 0)
+    C2 = torch.zeros(m2 * n2, dtype=torch.float64, device="cuda")
+    ex.exgemm_dev("N", "N", m2, n2, k2, 1.0, A2, k2, B2, n2, 0.0, C2, n2, 8, True)
+    torch.cuda.synchronize()
+    assert gemm_info(lib)[0] == 4
+    g3 = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g3, stream=s):
+            ex.exgemm_dev("N", "N", m2, n2, k2, 1.0, A2, k2, B2, n2, 0.0, C2, n2, 8, True)
+    for kind, p0, p1 in datasets:                # 18 moduli, 32, 15, scalar kernel
+        A2.copy_(ex.gen_dev(kind, m2 * k2, 61, p0, p1))
+        B2.copy_(ex.gen_dev(kind, k2 * n2, 62, p0, p1))
+        C2.fill_(-1.0)
+        g3.replay()
+        torch.cuda.synchronize()
+        want = oracle.exgemm("N", "N", m2, n2, k2, 1.0, A2.cpu().numpy(), k2, B2.cpu().numpy(), n2, 0.0,
+                             np.zeros(m2 * n2), n2, 0)
+        assert (_bits(C2.cpu().numpy()) == _bits(want)).all(), kind
     # growing the workspace during a capture is refused with an error instead of reallocating under the graph
     big = 1024
     Ab = ex.gen_dev("fpuniform", big * big, 53, 10, 0)
@@ -306,8 +433,9 @@ def same_bits(x, y):
     return np.float64(x).view(np.int64) == np.float64(y).view(np.int64)
 
 
-def test_exgemm_mfma_fallbacks(ex, oracle):
-    """Inputs the int8 slice path must refuse ON THE DEVICE (the predicated scalar kernel then does the work):
+@pytest.mark.parametrize("path", [0, 4])
+def test_exgemm_mfma_fallbacks(ex, oracle, path):
+    """Inputs the int8 paths (digit slices: mode 0 at this size; residues: mode 4) must refuse ON THE DEVICE (the predicated scalar kernel then does the work):
     subnormals, Inf/NaN, huge / tiny exponents; plus all-zero operands, rows/columns of zeros and signed zeros inside
     the fast path.  Always the oracle's bits."""
     lib = ex.load_library()
@@ -326,9 +454,13 @@ def test_exgemm_mfma_fallbacks(ex, oracle):
         if not (np.isfinite(a).all() and np.isfinite(b).all()):
             want = np.where(np.isfinite(ieee), want, ieee)
         c = c0.copy()
-        ex.exgemm("N", "N", m, n, k, 1.0, a, k, b, n, 0.0, c, n, 8, True)
-        used = gemm_info(lib)
-        assert want_fast is None or (used[0] == 2) == want_fast, used
+        lib.exblas_set_gemm_path(path)
+        try:
+            ex.exgemm("N", "N", m, n, k, 1.0, a, k, b, n, 0.0, c, n, 8, True)
+            used = gemm_info(lib)
+        finally:
+            lib.exblas_set_gemm_path(0)
+        assert want_fast is None or (used[0] == (4 if path == 4 else 2)) == want_fast, used
         ok = (_bits(c) == _bits(want)) | (np.isnan(c) & np.isnan(want))
         assert ok.all(), np.nonzero(~ok)[0][:5]
 
@@ -426,4 +558,8 @@ def test_exgemm_randomized_soak(ex):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_gemm.py"), "120", "7"],
                        capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "0 mismatches" in r.stdout, (r.stdout[-3000:], r.stderr[-2000:])
+    # the same cases with the residue path forced at every shape (by default it serves min(m, n) >= 192 only)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_gemm.py"), "120", "8"],
+                       capture_output=True, text=True, timeout=900, env=dict(os.environ, EXBLAS_GEMM_PATH="4"))
     assert r.returncode == 0 and "0 mismatches" in r.stdout, (r.stdout[-3000:], r.stderr[-2000:])

@@ -1,4 +1,5 @@
-"""Randomised soak of ExGEMM's int8 path against the oracle: python tools/stress_gemm.py [iterations] [seed].
+"""Randomised soak of ExGEMM's int8 paths against the oracle: python tools/stress_gemm.py [iterations] [seed].
+EXBLAS_GEMM_PATH=4 in the environment forces the residue path (blas3_crt.hip) at every shape, =2 the digit slices.
 Random shapes (ragged tiles, k across the 8192-per-pass boundary), transposes, leading dimensions, alpha/beta, operand
 families chosen independently for A and B (so every digit count 1..16 and every pairing occurs: unrolled bodies,
 generic body, multi-pass, scalar fallback), both rounding modes, now and then a non-finite or subnormal entry.
@@ -79,6 +80,6 @@ for it in range(iters):
     if it % 50 == 0:
         print(f"it {it}: {desc} [{time.time() - t0:.0f} s]", flush=True)
 lib.exblas_set_round_mode(0)
-print("paths (impl, digits A, digits B): count ->", dict(sorted(paths.items())))
+print("paths (impl, digits or bits of A, of B): count ->", dict(sorted(paths.items())))
 print(f"done: {iters} cases, {bad} mismatches, {time.time() - t0:.0f} s")
 sys.exit(1 if bad else 0)
