@@ -35,7 +35,7 @@ if ks:
 def short(name):
     # longest names first: k_stream_read2 must not be averaged into k_stream_read (it reads twice the bytes)
     for k in ("k_stream_read2", "k_stream_read", "k_exsum_segmented", "k_exsum", "k_exdot", "k_finalize", "k_gen",
-              "k_gemv_finish", "k_gemvN_fpe_sx", "k_gemvN_fpe", "k_gemvN_sa", "k_gemvT", "k_scale_x", "k_gemm_mfma", "k_gemm_i8g",
+              "k_gemv_finish", "k_gemvN_fpe_sx", "k_gemvN_fpe", "k_gemvN_sa", "k_gemvT", "k_scale_x", "k_gemm_mfma", "k_gemm_crt", "k_crt_finish", "k_crt_residues", "k_crt_decide", "k_gemm_i8g",
               "k_gemm_i8", "k_i8_slice_contig",
               "k_i8_slice_strided", "k_i8_finish", "k_i8_zero_w", "k_i8_decide", "k_gemm", "k_trsv", "k_dtrsv",
               "k_scan"):
@@ -44,7 +44,7 @@ def short(name):
     return None
 
 
-PREDICATED = {"k_gemm_i8", "k_gemm", "k_i8_finish", "k_i8_zero_w"}
+PREDICATED = {"k_gemm_i8", "k_gemm", "k_i8_finish", "k_i8_zero_w", "k_crt_finish"}
 means = collections.defaultdict(dict)
 for which, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     f = one(f"{which}/*/*_counter_collection.csv")
