@@ -202,6 +202,49 @@ __global__ void k_crt_decide(int *info, int clog2k, int lcap)
 // One workgroup per (64-vector tile, 64-k chunk) as in the digit slicers; a thread holds 16 consecutive k of one vector
 // as magnitudes + signs and walks the moduli: |X| mod p = (sum_t byte_t(|X|) * (256^t mod p)) mod p, four bytes per
 // v_dot4_u32_u8.  CONTIG: element (v, l) at src[v*ld + l] (A for 'N', B for 'T'); else at src[l*ld + v].
+template <bool CONTIG, int NW>
+__device__ __forceinline__ void crt_residues_body(const double *__restrict__ src, long long ld, int nvec, int len, double scale,
+                                                  int u, int v, int l0, int L, signed char *__restrict__ tile,
+                                                  size_t plane_stride)
+{
+    unsigned w[NW][16];
+    unsigned negmask = 0;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int l = l0 + e;
+        double x = 0.0;
+        if (v < nvec && l < len) x = scale * (CONTIG ? src[(long long)v * ld + l] : src[(long long)l * ld + v]);
+        const I128 X = to_fixed(fabs(x), u);
+        w[0][e] = (unsigned)X.lo;
+        if constexpr (NW > 1) w[1][e] = (unsigned)(X.lo >> 32);
+        if constexpr (NW > 2) w[2][e] = (unsigned)X.hi;
+        if constexpr (NW > 3) w[3][e] = (unsigned)((unsigned long long)X.hi >> 32);
+        negmask |= (x < 0.0 ? 1u : 0u) << e;
+    }
+#pragma unroll 1
+    for (int t = 0; t < L; ++t) {
+        const unsigned p = (unsigned)g_crt.p[t], hi = (p - 1u) >> 1;
+        const float invp = g_crt.invp[t];
+        unsigned c[NW];
+#pragma unroll
+        for (int j = 0; j < NW; ++j) c[j] = g_crt.c8[t][j];
+        union { v4i_t v; signed char b[16]; } pk;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            unsigned s = 0;
+#pragma unroll
+            for (int j = 0; j < NW; ++j) s = __builtin_amdgcn_udot4(w[j][e], c[j], s, false);
+            const unsigned q = (unsigned)((float)s * invp);  // s < 2^20: exact float; q = floor(s/p) or one less
+            unsigned rr = s - q * p;
+            rr = min(rr, rr - p);                            // rr >= p  ->  rr - p (unsigned wrap otherwise)
+            int sv = (int)rr - (rr > hi ? (int)p : 0);       // symmetric residue in [-(p-1)/2 .. (p-1)/2], p = 256: [-128, 127]
+            sv = ((negmask >> e) & 1u) ? -sv : sv;           // p = 256: -(-128) wraps to -128 = 128 mod 256
+            pk.b[e] = (signed char)sv;
+        }
+        *(v4i_t *)(tile + (size_t)t * plane_stride) = pk.v;
+    }
+}
+
 template <bool CONTIG>
 __global__ void __launch_bounds__(256) k_crt_residues(const double *__restrict__ src, long long ld, int nvec, int len,
                                                       double scale, const int *__restrict__ E,
@@ -214,43 +257,14 @@ __global__ void __launch_bounds__(256) k_crt_residues(const double *__restrict__
     const int r = CONTIG ? (threadIdx.x >> 2) : (threadIdx.x & 63), seg = CONTIG ? (threadIdx.x & 3) : (threadIdx.x >> 6);
     const int v = vt * I8_T + r, l0 = kc * I8_T + seg * 16;
     const int u = (v < nvec ? E[v] : 0) - need;
-    const int nw = (need + 31) >> 5;  // 32-bit words of |X| in use (wave-uniform)
-    unsigned w0[16], w1[16], w2[16], w3[16];
-    unsigned negmask = 0;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const int l = l0 + e;
-        double x = 0.0;
-        if (v < nvec && l < len) x = scale * (CONTIG ? src[(long long)v * ld + l] : src[(long long)l * ld + v]);
-        const bool neg = x < 0.0;
-        const I128 X = to_fixed(fabs(x), u);
-        w0[e] = (unsigned)X.lo;
-        w1[e] = (unsigned)(X.lo >> 32);
-        w2[e] = (unsigned)X.hi;
-        w3[e] = (unsigned)((unsigned long long)X.hi >> 32);
-        negmask |= (neg ? 1u : 0u) << e;
-    }
     signed char *tile = planes + ((size_t)vt * KC + kc) * I8_TILE + tile_off(r, seg * 16);
-    for (int t = 0; t < L; ++t) {
-        const unsigned p = (unsigned)g_crt.p[t], hi = (p - 1u) >> 1;
-        const float invp = g_crt.invp[t];
-        const unsigned c0 = g_crt.c8[t][0], c1 = g_crt.c8[t][1], c2 = g_crt.c8[t][2], c3 = g_crt.c8[t][3];
-        union { v4i_t v; signed char b[16]; } pk;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            unsigned s = __builtin_amdgcn_udot4(w0[e], c0, 0u, false);
-            if (nw > 1) s = __builtin_amdgcn_udot4(w1[e], c1, s, false);
-            if (nw > 2) s = __builtin_amdgcn_udot4(w2[e], c2, s, false);
-            if (nw > 3) s = __builtin_amdgcn_udot4(w3[e], c3, s, false);
-            const unsigned q = (unsigned)((float)s * invp);  // s < 2^20: exact float; q = floor(s/p) or one less
-            unsigned rr = s - q * p;
-            rr = min(rr, rr - p);                            // rr >= p  ->  rr - p (unsigned wrap otherwise)
-            int sv = (int)rr - (rr > hi ? (int)p : 0);       // symmetric residue in [-(p-1)/2 .. (p-1)/2], p = 256: [-128, 127]
-            sv = ((negmask >> e) & 1u) ? -sv : sv;           // p = 256: -(-128) wraps to -128 = 128 mod 256
-            pk.b[e] = (signed char)sv;
-        }
-        *(v4i_t *)(tile + (size_t)t * plane_stride) = pk.v;
-    }
+    const int nw = (need + 31) >> 5;  // 32-bit words of |X| in use (wave-uniform): the loops carry no branches
+#define CRT_RES(NW) crt_residues_body<CONTIG, NW>(src, ld, nvec, len, scale, u, v, l0, L, tile, plane_stride)
+    if (nw <= 1) CRT_RES(1);
+    else if (nw == 2) CRT_RES(2);
+    else if (nw == 3) CRT_RES(3);
+    else CRT_RES(4);
+#undef CRT_RES
 }
 
 // ---------------------------------------------------------------------------------------------
