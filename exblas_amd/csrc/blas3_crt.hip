@@ -435,6 +435,13 @@ __device__ __forceinline__ double crt_dmod(double z, double P, double invP)  // 
     return r;
 }
 
+// z mod P up to one multiple of P either way: a value in [-P, 2P) congruent to z.  Enough for the intermediate steps
+// (everything stays an exact integer far below 2^53; only the last reduction of a group must be canonical).
+__device__ __forceinline__ double crt_dmod_lazy(double z, double P, double invP)
+{
+    return fma(-floor(z * invP), P, z);
+}
+
 // Thread = (group of 4 rows, column): the L words R[t][g][j] hold the residues of its 4 entries, loaded two groups of
 // moduli ahead of their use.  Per group of three moduli: Garner inside the group gives the residue x_b modulo the
 // 24-bit super-modulus P_b; then the classical formula  value = sum_b y_b (M / P_b) - kappa M,  y_b = x_b (M / P_b)^-1
@@ -476,11 +483,11 @@ __device__ __forceinline__ void crt_finish_body(int L, int na, int nb, int g, in
             double x = r0;
             if (W == 3 || w >= 2) {
                 const double r1 = (double)((cur[1] >> (8 * o)) & 255u);
-                const double v1 = crt_dmod((r1 - r0) * i01, p1, ip1);
+                const double v1 = crt_dmod_lazy((r1 - r0) * i01, p1, ip1);
                 x = fma(p0, v1, r0);
                 if (W == 3 || w >= 3) {
                     const double r2 = (double)((cur[2] >> (8 * o)) & 255u);
-                    const double v2 = crt_dmod(((r2 - r0) * i02 - v1) * i12, p2, ip2);
+                    const double v2 = crt_dmod_lazy(((r2 - r0) * i02 - v1) * i12, p2, ip2);
                     x = fma(p01, v2, x);
                 }
             }
@@ -556,8 +563,8 @@ __global__ void __launch_bounds__(256) k_crt_finish(int row0, int row1, int n, c
 {
     if (info[INFO_PATH] != PATH_CRT) return;
     const int L = info[INFO_CRT_L], na = info[INFO_CRT_NA], nb = info[INFO_CRT_NB];
-    // words of M_L, plus one for the sum of up to 13 terms below M_L each
-    const int nw = ((g_crt.bits[L] + 32) >> 5) + 1;
+    // words that hold the sum of up to 13 terms below M_L each (4 bits of headroom)
+    const int nw = (g_crt.bits[L] + 1 + 4 + 31) >> 5;
     if (nw > NW || nw <= NWPREV) return;
     const long long loc = (long long)blockIdx.x * 256 + threadIdx.x;
     const int groups = (row1 - row0 + 3) >> 2;
@@ -661,8 +668,10 @@ hipError_t exgemm_crt_rows(const I8Plan &p, int row0, int row1, hipStream_t st)
 #define CRT_FIN(NW, NWPREV)                                                                                              \
     hipLaunchKernelGGL((k_crt_finish<NW, NWPREV>), dim3((unsigned)((groups * p.n + 255) / 256)), dim3(256), 0, st, row0,  \
                        row1, p.n, p.info, p.EA, p.EB, p.beta, p.c, (long long)p.ldc, p.round_mode, p.R, p.m4)
-    CRT_FIN(4, 0);
-    CRT_FIN(6, 4);
+    CRT_FIN(3, 0);
+    CRT_FIN(4, 3);
+    CRT_FIN(5, 4);
+    CRT_FIN(6, 5);
     CRT_FIN(8, 6);
     CRT_FIN(CRT_W32, 8);
 #undef CRT_FIN
