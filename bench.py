@@ -145,6 +145,7 @@ def timed_steps(ex, torch, dist, comm, op, buffers, fpe, ee, steps, warmup, worl
         one_step()
     drain()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    stride = nbuf + 1 if nbuf > 1 else 4
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -152,8 +153,10 @@ def timed_steps(ex, torch, dist, comm, op, buffers, fpe, ee, steps, warmup, worl
     t0 = time.perf_counter()
     for i in range(steps):
         # every event is one more packet in the queue between two streaming kernels (~3 us each): the kernel time is
-        # sampled on every fourth step instead of bracketing all of them
-        if i % 4 and steps >= 8:
+        # sampled on every `stride`-th step instead of bracketing all of them; the stride is coprime with the number of
+        # rotating buffers, so the samples visit every buffer (with a stride of 4 over 4 buffers the sampled kernel
+        # was always the one on buffer 0 -- for ExDOT that pair of vectors happened to stream 6 % faster than the rest)
+        if i % stride and steps >= 2 * stride:
             one_step()
         else:
             one_step(*ev[i])
@@ -163,7 +166,7 @@ def timed_steps(ex, torch, dist, comm, op, buffers, fpe, ee, steps, warmup, worl
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    timed = [p for i, p in enumerate(ev) if not (i % 4 and steps >= 8)]
+    timed = [p for i, p in enumerate(ev) if not (i % stride and steps >= 2 * stride)]
     kms = sum(a.elapsed_time(b) for a, b in timed) / max(len(timed), 1)
     ex.set_accumulator_slot(0)
     if state["last"] is not rec:

@@ -36,7 +36,7 @@ C_ABI_SYMBOLS = [
     "exblas_comm_destroy", "exblas_comm_rank", "exblas_comm_size", "exblas_shard_range",
     "exblas_exsum_allreduce_dev", "exblas_exdot_allreduce_dev", "exblas_allreduce_finish_dev",
     "exblas_exgemv_sharded_dev", "exblas_exgemm_sharded_dev", "exblas_last_gemm_info", "exblas_set_gemm_max_slices",
-    "exblas_set_gemm_max_moduli",
+    "exblas_set_gemm_max_moduli", "exblas_crt_selftest",
     "exblas_set_host_devices",
 ]
 
@@ -119,6 +119,8 @@ def load_library():
     L.exblas_set_gemm_max_slices.restype = None
     L.exblas_set_gemm_max_moduli.argtypes = [i32]
     L.exblas_set_gemm_max_moduli.restype = None
+    L.exblas_crt_selftest.argtypes = [i32, C.c_uint]
+    L.exblas_crt_selftest.restype = i32
     L.exblas_comm_unique_id.argtypes = [vp]
     L.exblas_comm_init_rccl.argtypes = [C.POINTER(vp), i32, i32, vp]
     L.exblas_comm_adopt_rccl.argtypes = [C.POINTER(vp), vp, i32, i32]

@@ -165,6 +165,108 @@ const CrtTables &crt_tables_host()
 
 }  // namespace
 
+__host__ __device__ __forceinline__ double crt_dmod(double z, double P, double invP)  // z mod P for |z| < 2^50, P < 2^24
+{
+    const double q = floor(z * invP);
+    double r = fma(-q, P, z);  // exact; q is off by at most one
+    r = r < 0.0 ? r + P : r;
+    r = r >= P ? r - P : r;
+    return r;
+}
+
+// z mod P up to one multiple of P either way: a value in [-P, 2P) congruent to z.  Enough for the intermediate steps
+// (everything stays an exact integer far below 2^53; only the last reduction of a group must be canonical).
+__host__ __device__ __forceinline__ double crt_dmod_lazy(double z, double P, double invP)
+{
+    return fma(-floor(z * invP), P, z);
+}
+
+// Thread = (group of 4 rows, column): the L words R[t][g][j] hold the residues of its 4 entries, loaded two groups of
+// moduli ahead of their use.  Per group of three moduli: Garner inside the group gives the residue x_b modulo the
+// 24-bit super-modulus P_b; then the classical formula  value = sum_b y_b (M / P_b) - kappa M,  y_b = x_b (M / P_b)^-1
+// mod P_b:  the big products in 32-bit words, kappa = round(sum_b y_b / P_b) in fp64 -- exact because |value| / M < 1/4
+// (k_crt_decide) while the fraction sum is good to 1e-14.  The table entries of a group are wave-uniform scalars, read
+// once for the four entries.
+// Host mirror of k_crt_finish's arithmetic over the same tables (CPU-only check of the table generator and of the
+// reconstruction formulas, tests/test_abi.py): random integers |S| < M_L / 4 for every L -> residues -> groups ->
+// classical CRT sum -> minus kappa M_L; the 320-bit two's-complement result must be S again.
+static int crt_selftest_host(int cases, unsigned seed)
+{
+    const CrtTables &t = crt_tables_host();
+    unsigned long long rng = 0x9e3779b97f4a7c15ull * (seed + 1);
+    auto next = [&]() {
+        rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17;
+        return (uint32_t)(rng >> 16);
+    };
+    int bad = 0;
+    for (int L = 1; L <= CRT_LMAX; ++L)
+        for (int cs = 0; cs < cases; ++cs) {
+            // magnitude below 2^(bits[L] - 2) <= M_L / 4, random sign; a few edge magnitudes first
+            const int mbits = t.bits[L] - 2;
+            Big mag;
+            if (mbits > 0 && cs != 0) {
+                for (int i = 0; i < CRT_W32; ++i) mag.w[i] = cs == 1 ? 0xffffffffu : next();
+                for (int i = 0; i < CRT_W32 + 2; ++i) {
+                    const int lo = 32 * i;
+                    if (lo >= mbits) mag.w[i] = 0;
+                    else if (lo + 32 > mbits) mag.w[i] &= (1u << (mbits - lo)) - 1u;
+                }
+            }
+            const bool neg = (cs & 1) && mag.bitlen() > 0;
+            const int G = (L + 2) / 3, wlast = L - 3 * (G - 1);
+            uint32_t acc[CRT_W32] = {0};
+            double phi = 0.0;
+            for (int b = 0; b < G; ++b) {
+                const int w = b == G - 1 ? wlast : 3;
+                double r[3] = {0, 0, 0};
+                for (int j = 0; j < w; ++j) {
+                    const uint32_t p = (uint32_t)t.p[3 * b + j];
+                    uint32_t m = mag.mod_small(p);
+                    if (neg && m) m = p - m;
+                    r[j] = (double)m;
+                }
+                double x = r[0];
+                if (w >= 2) {
+                    const double v1 = crt_dmod_lazy((r[1] - r[0]) * t.gi01[b], t.gp[b][1], t.gip[b][1]);
+                    x = fma(t.gp[b][0], v1, r[0]);
+                    if (w >= 3) {
+                        const double v2 = crt_dmod_lazy(((r[2] - r[0]) * t.gi02[b] - v1) * t.gi12[b], t.gp[b][2], t.gip[b][2]);
+                        x = fma(t.P[b][1], v2, x);
+                    }
+                }
+                const double y = crt_dmod(x * t.wc[L][b], t.P[b][w - 1], t.invP[b][w - 1]);
+                phi = fma(y, t.invP[b][w - 1], phi);
+                const uint32_t yb = (uint32_t)y;
+                uint64_t carry = 0;
+                for (int i = 0; i < CRT_W32; ++i) {
+                    const uint64_t v = (uint64_t)t.MP[L][b][i] * yb + acc[i] + carry;
+                    acc[i] = (uint32_t)v;
+                    carry = v >> 32;
+                }
+            }
+            const uint32_t kappa = (uint32_t)rint(phi);
+            uint64_t mc = 0, borrow = 0;
+            for (int i = 0; i < CRT_W32; ++i) {
+                const uint64_t prod = (uint64_t)t.M[L][i] * kappa + mc;
+                mc = prod >> 32;
+                const uint64_t d = (uint64_t)acc[i] - (prod & 0xffffffffull) - borrow;
+                acc[i] = (uint32_t)d;
+                borrow = (d >> 32) & 1ull;
+            }
+            // expected: two's complement of +-mag in CRT_W32 words
+            uint32_t want[CRT_W32];
+            uint64_t c = neg ? 1 : 0;
+            for (int i = 0; i < CRT_W32; ++i) {
+                const uint64_t v = (uint64_t)(neg ? ~mag.w[i] : mag.w[i]) + c;
+                want[i] = (uint32_t)v;
+                c = neg ? (v >> 32) : 0;
+            }
+            for (int i = 0; i < CRT_W32; ++i)
+                if (want[i] != acc[i]) { ++bad; break; }
+        }
+    return bad;
+}
+
 // copies the tables into the current device's copy of g_crt (context creation: never inside a stream capture)
 hipError_t crt_tables_upload()
 {
@@ -426,28 +528,6 @@ __global__ void __launch_bounds__(256, 1) k_gemm_crt(int n, int row_end, int ty0
 // ---------------------------------------------------------------------------------------------
 // reconstruct and round
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ double crt_dmod(double z, double P, double invP)  // z mod P for |z| < 2^50, P < 2^24
-{
-    const double q = floor(z * invP);
-    double r = fma(-q, P, z);  // exact; q is off by at most one
-    r = r < 0.0 ? r + P : r;
-    r = r >= P ? r - P : r;
-    return r;
-}
-
-// z mod P up to one multiple of P either way: a value in [-P, 2P) congruent to z.  Enough for the intermediate steps
-// (everything stays an exact integer far below 2^53; only the last reduction of a group must be canonical).
-__device__ __forceinline__ double crt_dmod_lazy(double z, double P, double invP)
-{
-    return fma(-floor(z * invP), P, z);
-}
-
-// Thread = (group of 4 rows, column): the L words R[t][g][j] hold the residues of its 4 entries, loaded two groups of
-// moduli ahead of their use.  Per group of three moduli: Garner inside the group gives the residue x_b modulo the
-// 24-bit super-modulus P_b; then the classical formula  value = sum_b y_b (M / P_b) - kappa M,  y_b = x_b (M / P_b)^-1
-// mod P_b:  the big products in 32-bit words, kappa = round(sum_b y_b / P_b) in fp64 -- exact because |value| / M < 1/4
-// (k_crt_decide) while the fraction sum is good to 1e-14.  The table entries of a group are wave-uniform scalars, read
-// once for the four entries.
 // NW = 32-bit words the sums are carried in (a bucket of the width of M_L): the inner loops carry no branches
 template <int NW>
 __device__ __forceinline__ void crt_finish_body(int L, int na, int nb, int g, int gj, int row1, const unsigned *__restrict__ rp,
@@ -679,3 +759,6 @@ hipError_t exgemm_crt_rows(const I8Plan &p, int row0, int row1, hipStream_t st)
 }
 
 }  // namespace exb
+
+// CPU-only: 0 = the tables reconstruct `cases` random integers per modulus count (tests/test_abi.py)
+extern "C" int exblas_crt_selftest(int cases, unsigned seed) { return exb::crt_selftest_host(cases, seed); }

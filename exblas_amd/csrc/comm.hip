@@ -405,7 +405,7 @@ int exblas_exgemm_sharded_dev(exblas_comm_t *cm, char transa, char transb, int m
     if (!cm || m < 0 || n < 0 || k < 0 || ldc < n) return (int)hipErrorInvalidValue;
     if (m == 0 || n == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    const bool ta = (transa == 'T' || transa == 't'), tb = (transb == 'T' || transb == 't');
+    const bool tb = (transb == 'T' || transb == 't');
     std::lock_guard<std::mutex> lk(cm->mu);
     int rc = 0;
     const bool multi = cm->nranks > 1 || (cm->kind == 0 && comm_force());

@@ -93,6 +93,9 @@ void exblas_set_gemm_max_moduli(int l);
  * per element pair).  Synchronises the device when the decision was taken there.  exblas_last_gemm_slices() =
  * max(out[1], out[2]) for the slice paths, out[3] for residues, 0 for the scalar kernel. */
 int exblas_last_gemm_info(int *out8);
+/* CPU-only self-test of the residue path's constant tables and reconstruction formulas: `cases` random integers per
+ * modulus count through a host mirror of the device arithmetic; returns the number of failures (0 = pass). */
+int exblas_crt_selftest(int cases, unsigned seed);
 int exblas_last_gemm_slices(void);
 /* Makes the *_dev layer's workspace at least `bytes` large (see "Workspace and hipGraphs" above). */
 int exblas_reserve_workspace(size_t bytes);

@@ -70,3 +70,13 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert not bad.search(txt), (f, "uses oracle code")
+
+
+def test_residue_gemm_tables_selftest(lib):
+    """The residue ExGEMM path (blas3_crt.hip) reconstructs an integer from its residues modulo up to 39 coprime 8-bit
+    moduli with constant tables generated on the host.  exblas_crt_selftest runs a host mirror of the device
+    arithmetic (Garner inside groups of three, classical CRT across the 24-bit super-moduli, fp64 fraction sum for the
+    multiple of M) over those tables: 200 random integers |S| < M_L / 4 per modulus count L = 1..39, no GPU involved.
+    The GPU parity tests (tests/test_gpu_blas23.py::test_exgemm_residue_path_*) check the kernels end to end."""
+    assert lib.exblas_crt_selftest(200, 1) == 0
+    assert lib.exblas_crt_selftest(50, 12345) == 0
