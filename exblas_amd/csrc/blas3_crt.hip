@@ -748,12 +748,16 @@ hipError_t exgemm_crt_rows(const I8Plan &p, int row0, int row1, hipStream_t st)
 #define CRT_FIN(NW, NWPREV)                                                                                              \
     hipLaunchKernelGGL((k_crt_finish<NW, NWPREV>), dim3((unsigned)((groups * p.n + 255) / 256)), dim3(256), 0, st, row0,  \
                        row1, p.n, p.info, p.EA, p.EB, p.beta, p.c, (long long)p.ldc, p.round_mode, p.R, p.m4)
-    CRT_FIN(3, 0);
-    CRT_FIN(4, 3);
-    CRT_FIN(5, 4);
-    CRT_FIN(6, 5);
-    CRT_FIN(8, 6);
-    CRT_FIN(CRT_W32, 8);
+    if (groups * p.n < (1 << 18)) {
+        CRT_FIN(CRT_W32, 0);  // small products are launch-bound: one kernel for every width instead of six candidates
+    } else {
+        CRT_FIN(3, 0);
+        CRT_FIN(4, 3);
+        CRT_FIN(5, 4);
+        CRT_FIN(6, 5);
+        CRT_FIN(8, 6);
+        CRT_FIN(CRT_W32, 8);
+    }
 #undef CRT_FIN
     return hipGetLastError();
 }
