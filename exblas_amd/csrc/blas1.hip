@@ -176,9 +176,13 @@ __global__ void __launch_bounds__(BLOCK) k_exsum_strided(const double *__restric
     double fpe[N > 0 ? N : 1];
 #pragma unroll
     for (int i = 0; i < (N > 0 ? N : 1); ++i) fpe[i] = 0.0;
-    for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (long long)gridDim.x * BLOCK) {
-        double x[1] = {a[i * inca]};
-        fpe_absorb<N, false, COPIES, 1>(fpe, x, 0, col, flags);
+    // four independent loads in flight per lane (a strided element is its own cache line: latency, not bandwidth)
+    const long long T = (long long)gridDim.x * BLOCK;
+    for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += 4 * T) {
+        double x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) x[u] = i + u * T < n ? a[(i + u * T) * inca] : 0.0;
+        fpe_absorb<N, false, COPIES, 4>(fpe, x, 0, col, flags);
     }
     fpe_flush<N, COPIES>(fpe, col, flags);
     block_epilogue<COPIES>(s_acc, flags, gacc, gflags, ngroups);
@@ -331,10 +335,18 @@ __global__ void __launch_bounds__(BLOCK) k_exdot_strided(const double *__restric
     double fpe[N > 0 ? N : 1];
 #pragma unroll
     for (int i = 0; i < (N > 0 ? N : 1); ++i) fpe[i] = 0.0;
-    for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (long long)gridDim.x * BLOCK) {
-        double x[1], e[1];
-        x[0] = two_prod(a[i * inca], b[i * incb], e[0]);
-        fpe_absorb_prod<N, false, 1>(fpe, x, e, sink);
+    const long long T = (long long)gridDim.x * BLOCK;
+    for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += 4 * T) {
+        double va[4], vb[4], x[4], e[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool in = i + u * T < n;
+            va[u] = in ? a[(i + u * T) * inca] : 0.0;
+            vb[u] = in ? b[(i + u * T) * incb] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) x[u] = two_prod(va[u], vb[u], e[u]);
+        fpe_absorb_prod<N, false, 4>(fpe, x, e, sink);
     }
     fpe_flush<N, COPIES>(fpe, col, flags);
     block_epilogue<COPIES>(s_acc, flags, gacc, gflags, ngroups);

@@ -63,7 +63,13 @@ static __global__ void __launch_bounds__(256) k_scan_contig(const double *__rest
     ScanAcc s;
     s.init();
     const double *q = p + (long long)v * ldv;
-    for (int i = threadIdx.x; i < len; i += 256) s.add(scale * q[i]);
+    for (int i = threadIdx.x; i < len; i += 1024) {  // four loads in flight per thread
+        double w[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) w[u] = i + 256 * u < len ? q[i + 256 * u] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s.add(scale * w[u]);
+    }
     red[threadIdx.x] = s;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
@@ -84,7 +90,13 @@ static __global__ void __launch_bounds__(256) k_scan_strided(const double *__res
     const int i0 = blockIdx.y * per, i1 = min(len, i0 + per);
     ScanAcc s;
     s.init();
-    for (int i = i0; i < i1; ++i) s.add(scale * p[(long long)i * ldv + v]);
+    for (int i = i0; i < i1; i += 4) {  // four loads in flight per thread
+        double w[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) w[u] = i + u < i1 ? p[(long long)(i + u) * ldv + v] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s.add(scale * w[u]);
+    }
     scan_publish(s, &vmax[v], &vlsb[v], info);
 }
 
