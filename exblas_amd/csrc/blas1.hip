@@ -456,7 +456,8 @@ static inline int grid_for(const Ctx &c, long long work_items, long long per_blo
     long long want = (work_items + per_block - 1) / per_block;
     long long cap = (long long)c.num_cu * blocks_per_cu;
     if (want < 1) want = 1;
-    return (int)(want < cap ? want : cap);
+    if (want >= cap) return (int)max(1ll, cap + c.grid_adj);
+    return (int)want;
 }
 
 template <int N, bool EE, int COPIES, int U, bool NT, bool PF, int ZM = 0>
@@ -504,6 +505,12 @@ template <int N, bool EE, int COPIES, int U, bool NT, bool PF, int WPS = 1, bool
 static void run_exdot(Ctx &c, const double *a, const double *b, long long n, hipStream_t st)
 {
     int grid = grid_for(c, n, (long long)BLOCK * 2 * U, c.bpc_dot);
+    // An ODD number of workgroups: a workgroup's successive tiles (grid tiles = grid x 16 KiB apart) then walk through
+    // the 32 KiB period with which the two streams' addresses compete for HBM channels, whatever b - a is.  With the
+    // even grid (32 x 256) the step time at n = 2^28 depended on the relative placement of the two vectors, 0.625 ms
+    // (b - a = 16 KiB mod 32 KiB) to 0.667 ms (0 mod 32 KiB); odd: 0.625-0.635 ms for every placement
+    // (tools/dot_align.py, profiles/r02_exdot_placement.log).
+    if (grid > c.num_cu && !(grid & 1)) grid += 1;
     hipLaunchKernelGGL((k_exdot<N, EE, COPIES, U, NT, PF, WPS, HALVES, ZM>), dim3(grid), dim3(BLOCK), 0, st, a, b, n, c.gacc,
                        c.gflags, c.ngroups);
 }

@@ -100,6 +100,7 @@ Ctx &ctx(int device, int layer)
         c.bpc_sa = env_int("EXBLAS_BPC_SA", 3);
         c.bpc_heavy = env_int("EXBLAS_BPC_HEAVY", 4);
         c.ngroups = env_int("EXBLAS_NGROUPS", 32);
+        c.grid_adj = env_int("EXBLAS_GRID_ADJ", 0);
         if (c.ngroups < 1) c.ngroups = 1;
         c.variant = env_int("EXBLAS_VARIANT", 0);
         c.gemm_path = env_int("EXBLAS_GEMM_PATH", 0);
@@ -107,6 +108,7 @@ Ctx &ctx(int device, int layer)
             const Ctx &z = g_ctx[0][device];
             c.blocks_per_cu = z.blocks_per_cu; c.bpc_sum = z.bpc_sum; c.bpc_dot = z.bpc_dot; c.bpc_sa = z.bpc_sa;
             c.bpc_heavy = z.bpc_heavy;
+            c.grid_adj = z.grid_adj;
             c.ngroups = z.ngroups; c.variant = z.variant; c.gemm_path = z.gemm_path;
             c.gemm_max_slices = z.gemm_max_slices;
             c.gemm_max_moduli = z.gemm_max_moduli;

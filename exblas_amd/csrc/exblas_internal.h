@@ -20,6 +20,7 @@ struct Ctx {
     int bpc_sa = 3;          // superaccumulator-only ExSUM (LDS-atomic bound; 3/CU: 6.65 TB/s, 2/CU: 6.0)
     int bpc_heavy = 4;       // ExSUM variants without early exit, N >= 5 (VALU-latency-bound)
     int ngroups = 32;        // EXBLAS_NGROUPS: global group accumulators the blocks add into
+    int grid_adj = 0;        // EXBLAS_GRID_ADJ: workgroups added to the grid of the streaming ExSUM / ExDOT kernels
     int variant = 0;         // tuning variant of the production kernels (exblas_set_tuning)
     // which ExGEMM implementation the last call used.  The int8 path decides on the device: gemm_info_dev then points
     // at its info block (read lazily, with a synchronisation, by exblas_last_gemm_info); otherwise the host knows.

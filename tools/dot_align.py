@@ -10,7 +10,8 @@ n = 1 << log2n
 ex.load_library().exblas_hip_init(-1)
 src_a = ex.gen_dev("ill_cond", n, 1, 1e32, 0)
 src_b = ex.gen_dev("ill_cond", n, 2, 1e32, 0)
-for pad in (0, 256, 1024, 4096, 16384, 65536, 1 << 20, (1 << 20) + 4096, 3 << 19):
+pads = [int(v) for v in sys.argv[2].split(',')] if len(sys.argv) > 2 else [0, 256, 1024, 4096, 16384, 65536, 1 << 20, (1 << 20) + 4096, 3 << 19]
+for pad in pads:
     pairs = []
     for j in range(3):
         blob = torch.empty(2 * n + (4 << 20) // 8, dtype=torch.float64, device="cuda")
