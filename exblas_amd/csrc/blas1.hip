@@ -468,6 +468,9 @@ static void run_exsum(Ctx &c, const double *a, long long n, hipStream_t st)
     // more waves per SIMD to hide it
     const int bpc = N == 0 ? c.bpc_sa : ((!EE && N >= 5) ? c.bpc_heavy : c.bpc_sum);
     int grid = grid_for(c, n, (long long)BLOCK * 2 * U, bpc);
+    // an odd number of workgroups (one resident slot left idle): the tiles a workgroup has in flight are grid x 16 KiB
+    // apart, and with an even grid they compete for the same HBM channels -- 865 against 855 Gelem/s at n = 2^28
+    if (grid == c.num_cu * bpc && grid > 1 && !(grid & 1)) grid -= 1;
     hipLaunchKernelGGL((k_exsum<N, EE, COPIES, U, NT, PF, ZM>), dim3(grid), dim3(BLOCK), 0, st, a, n, c.gacc, c.gflags,
                        c.ngroups, c.variant == 9 ? 1 : 0);
 }
