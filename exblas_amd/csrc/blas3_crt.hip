@@ -634,25 +634,36 @@ __device__ __forceinline__ void crt_finish_body(int L, int na, int nb, int g, in
     }
 }
 
-// one kernel per bucket (its own register budget); the launches of the other buckets exit at once
-template <int NW, int NWPREV>
+// Two kernels (narrow sums: up to 6 words; wide: 8 or 10), each with the register budget of its widest body; the launch
+// the data does not need exits at once (an empty launch of 65536 workgroups costs ~20 us: six candidates were too many).
+template <bool WIDE>
 __global__ void __launch_bounds__(256) k_crt_finish(int row0, int row1, int n, const int *__restrict__ info,
                                                     const int *__restrict__ EA, const int *__restrict__ EB, double beta,
                                                     double *__restrict__ c, long long ldc, int round_mode,
-                                                    const unsigned *__restrict__ R, int m4)
+                                                    const unsigned *__restrict__ R, int m4, int all)
 {
     if (info[INFO_PATH] != PATH_CRT) return;
     const int L = info[INFO_CRT_L], na = info[INFO_CRT_NA], nb = info[INFO_CRT_NB];
     // words that hold the sum of up to 13 terms below M_L each (4 bits of headroom)
     const int nw = (g_crt.bits[L] + 1 + 4 + 31) >> 5;
-    if (nw > NW || nw <= NWPREV) return;
+    if (!all && (nw > 6) != WIDE) return;
     const long long loc = (long long)blockIdx.x * 256 + threadIdx.x;
     const int groups = (row1 - row0 + 3) >> 2;
     if (loc >= (long long)groups * n) return;
     const int g = (row0 >> 2) + (int)(loc / n), gj = (int)(loc % n);
     const size_t stride = (size_t)m4 * n;
     const unsigned *rp = R + (size_t)g * n + gj;
-    crt_finish_body<NW>(L, na, nb, g, gj, row1, rp, stride, EA, EB, beta, c, ldc, round_mode);
+#define CRT_FIN(NW) crt_finish_body<NW>(L, na, nb, g, gj, row1, rp, stride, EA, EB, beta, c, ldc, round_mode)
+    if constexpr (WIDE) {
+        if (nw <= 8 && !all) CRT_FIN(8);
+        else CRT_FIN(CRT_W32);
+    } else {
+        if (nw <= 3) CRT_FIN(3);
+        else if (nw == 4) CRT_FIN(4);
+        else if (nw == 5) CRT_FIN(5);
+        else CRT_FIN(6);
+    }
+#undef CRT_FIN
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -745,18 +756,14 @@ hipError_t exgemm_crt_rows(const I8Plan &p, int row0, int row1, hipStream_t st)
                            gy, gx, p.KC, kc0, min(p.KC, kc0 + CRT_KPASS), p.PA, p.PB, p.plane_a, p.plane_b, p.info, p.R,
                            p.m4);
     const long long groups = (row1 - row0 + 3) / 4;
-#define CRT_FIN(NW, NWPREV)                                                                                              \
-    hipLaunchKernelGGL((k_crt_finish<NW, NWPREV>), dim3((unsigned)((groups * p.n + 255) / 256)), dim3(256), 0, st, row0,  \
-                       row1, p.n, p.info, p.EA, p.EB, p.beta, p.c, (long long)p.ldc, p.round_mode, p.R, p.m4)
+#define CRT_FIN(WIDE, ALL)                                                                                               \
+    hipLaunchKernelGGL((k_crt_finish<WIDE>), dim3((unsigned)((groups * p.n + 255) / 256)), dim3(256), 0, st, row0, row1,  \
+                       p.n, p.info, p.EA, p.EB, p.beta, p.c, (long long)p.ldc, p.round_mode, p.R, p.m4, ALL)
     if (groups * p.n < (1 << 18)) {
-        CRT_FIN(CRT_W32, 0);  // small products are launch-bound: one kernel for every width instead of six candidates
+        CRT_FIN(true, 1);  // small products are launch-bound: one kernel (10 words) for every width
     } else {
-        CRT_FIN(3, 0);
-        CRT_FIN(4, 3);
-        CRT_FIN(5, 4);
-        CRT_FIN(6, 5);
-        CRT_FIN(8, 6);
-        CRT_FIN(CRT_W32, 8);
+        CRT_FIN(false, 0);
+        CRT_FIN(true, 0);
     }
 #undef CRT_FIN
     return hipGetLastError();
