@@ -109,7 +109,7 @@ __global__ void __launch_bounds__(256) k_scale_x(int n, double alpha, const doub
 template <int N, bool EE, int U = 8>
 __global__ void __launch_bounds__(GV_BLOCK) k_gemvN_fpe_sx(int m, int n, const double *__restrict__ a, long long lda,
                                                            const double *__restrict__ xa, int kper,
-                                                           double *__restrict__ part, long long *__restrict__ ws)
+                                                           double *__restrict__ part, long long *__restrict__ ws, int il)
 {
     const int tid = threadIdx.x;
     const long long r0 = ((long long)blockIdx.x * GV_BLOCK + tid) * 2;
@@ -121,9 +121,14 @@ __global__ void __launch_bounds__(GV_BLOCK) k_gemvN_fpe_sx(int m, int n, const d
     for (int i = 0; i < N; ++i) f0[i] = f1[i] = 0.0;
     GlobalSink s0{ws + (v0 ? r0 : 0) * SET_WORDS}, s1{ws + (v0 ? r0 + 1 : 0) * SET_WORDS};
     if (v0) {
-        const double *col = a + r0 + lda * k0;
-        int k = k0;
-        for (; k + U <= k1; k += U, col += lda * U) {
+        // il: the k splits take the groups of U columns round-robin (split ks: groups ks, ks + KS, ...) instead of one
+        // contiguous range each: the splits that run side by side then differ in LOW bits of the column offset (with a
+        // power-of-two lda the high ones do not reach the HBM channel / bank hash)
+        int k = il ? ks * U : k0;
+        const int kend = il ? n : k1;
+        const long long kstep = il ? (long long)KS * U : U;
+        const double *col = a + r0 + lda * k;
+        for (; k + U <= kend; k += (int)kstep, col += lda * kstep) {
             double ax[U], ay[U], xs[U];
 #pragma unroll
             for (int j = 0; j < U; ++j) {
@@ -140,7 +145,7 @@ __global__ void __launch_bounds__(GV_BLOCK) k_gemvN_fpe_sx(int m, int n, const d
             for (int j = 0; j < U; ++j) p[j] = two_prod(ay[j], xs[j], e[j]);
             fpe_absorb_prod<N, EE, U, GlobalSink, 1>(f1, p, e, s1);
         }
-        for (; k < k1; ++k, col += lda) {
+        for (; k < kend; ++k, col += lda) {  // partial last group (il: only the split whose turn it is gets here)
             const d2_t r = ld2<true>((const d2_t *)col);
             const double xv = xa[k];
             double p[1], e[1];
@@ -427,7 +432,7 @@ static hipError_t gemvN_fpe(Ctx &c, int m, int n, double alpha, const double *a,
         // the LDS-staged kernel below (variant 6) in one process: 1.40-1.45 ms against 1.41-1.48 at 32768^2
         hipLaunchKernelGGL(k_scale_x, dim3((n + 255) / 256), dim3(256), 0, st, n, alpha, x, (long long)incx, xa);
         hipLaunchKernelGGL((k_gemvN_fpe_sx<N, EE, 8>), grid, dim3(GV_BLOCK), 0, st, m, n, a, (long long)lda, xa, kper, part,
-                           ws);
+                           ws, c.variant == 9 ? 0 : 1);
     } else if (vec && c.variant == 1)
         hipLaunchKernelGGL((k_gemvN_fpe<N, EE, true, 4>), grid, dim3(GV_BLOCK), 0, st, m, n, alpha, a, (long long)lda, x,
                            (long long)incx, kper, part, ws);

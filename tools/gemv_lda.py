@@ -7,7 +7,7 @@ m = n = 32768
 ex.load_library().exblas_hip_init(-1)
 x = ex.gen_dev("fpuniform", n, 12, 10.0, 0.0)
 y = ex.gen_dev("fpuniform", m, 13, 10.0, 0.0)
-for pad in (0, 16, 512):
+for pad in (0, 16, 512, 32768):
     lda = m + pad
     a = ex.gen_dev("fpuniform", lda * n, 11, 10.0, 0.0)
     for tr in ("N", "T"):
