@@ -121,31 +121,59 @@ __global__ void __launch_bounds__(GV_BLOCK) k_gemvN_fpe_sx(int m, int n, const d
     for (int i = 0; i < N; ++i) f0[i] = f1[i] = 0.0;
     GlobalSink s0{ws + (v0 ? r0 : 0) * SET_WORDS}, s1{ws + (v0 ? r0 + 1 : 0) * SET_WORDS};
     if (v0) {
-        // il: the k splits take the groups of U columns round-robin (split ks: groups ks, ks + KS, ...) instead of one
-        // contiguous range each: the splits that run side by side then differ in LOW bits of the column offset (with a
-        // power-of-two lda the high ones do not reach the HBM channel / bank hash)
-        int k = il ? ks * U : k0;
-        const int kend = il ? n : k1;
-        const long long kstep = il ? (long long)KS * U : U;
-        const double *col = a + r0 + lda * k;
-        for (; k + U <= kend; k += (int)kstep, col += lda * kstep) {
-            double ax[U], ay[U], xs[U];
+        // il = 1: the k splits take the groups of U columns round-robin (split ks: groups ks, ks + KS, ...) instead of
+        // one contiguous range each (+1-2 %).  il = 2: in addition a group is every SECOND column of a block of 2U (even
+        // ones, then odd ones), so the loads a wave has in flight are 2 lda apart -- the 256 KiB column stride of
+        // lda = 32768 is the one that costs 9 % (tools/gemv_lda.py), 512 KiB does not.
+        static_assert(U == 8, "column groups are blocks of 16");
+        const int cs = il == 2 ? 2 : 1;                          // column step inside a group
+        const int nfull = il == 2 ? (n / (2 * U)) * 2 * U : (n / U) * U;  // columns covered by whole groups
+        auto group_k = [&](int gg) { return il == 2 ? (gg >> 1) * 2 * U + (gg & 1) : gg * U; };
+        if (il) {
+            for (int g = ks; g < nfull / U; g += KS) {
+                const int k = group_k(g);
+                const double *col = a + r0 + lda * k;
+                double ax[U], ay[U], xs[U];
 #pragma unroll
-            for (int j = 0; j < U; ++j) {
-                const d2_t r = ld2<true>((const d2_t *)(col + lda * j));
-                ax[j] = r.x;
-                ay[j] = r.y;
-                xs[j] = xa[k + j];  // uniform address: scalar load
+                for (int j = 0; j < U; ++j) {
+                    const d2_t r = ld2<true>((const d2_t *)(col + lda * (cs * j)));
+                    ax[j] = r.x;
+                    ay[j] = r.y;
+                    xs[j] = xa[k + cs * j];  // uniform address: scalar load
+                }
+                double p[U], e[U];
+#pragma unroll
+                for (int j = 0; j < U; ++j) p[j] = two_prod(ax[j], xs[j], e[j]);
+                fpe_absorb_prod<N, EE, U, GlobalSink, 1>(f0, p, e, s0);
+#pragma unroll
+                for (int j = 0; j < U; ++j) p[j] = two_prod(ay[j], xs[j], e[j]);
+                fpe_absorb_prod<N, EE, U, GlobalSink, 1>(f1, p, e, s1);
             }
-            double p[U], e[U];
-#pragma unroll
-            for (int j = 0; j < U; ++j) p[j] = two_prod(ax[j], xs[j], e[j]);
-            fpe_absorb_prod<N, EE, U, GlobalSink, 1>(f0, p, e, s0);
-#pragma unroll
-            for (int j = 0; j < U; ++j) p[j] = two_prod(ay[j], xs[j], e[j]);
-            fpe_absorb_prod<N, EE, U, GlobalSink, 1>(f1, p, e, s1);
         }
-        for (; k < kend; ++k, col += lda) {  // partial last group (il: only the split whose turn it is gets here)
+        // what the groups do not cover: il == 0: this split's whole range; otherwise the last columns, split 0's job
+        int k = il ? nfull : k0;
+        const int kend = il ? (ks == 0 ? n : 0) : k1;
+        const double *col = a + r0 + lda * k;
+        if (!il) {
+            for (; k + U <= kend; k += U, col += lda * U) {
+                double ax[U], ay[U], xs[U];
+#pragma unroll
+                for (int j = 0; j < U; ++j) {
+                    const d2_t r = ld2<true>((const d2_t *)(col + lda * j));
+                    ax[j] = r.x;
+                    ay[j] = r.y;
+                    xs[j] = xa[k + j];
+                }
+                double p[U], e[U];
+#pragma unroll
+                for (int j = 0; j < U; ++j) p[j] = two_prod(ax[j], xs[j], e[j]);
+                fpe_absorb_prod<N, EE, U, GlobalSink, 1>(f0, p, e, s0);
+#pragma unroll
+                for (int j = 0; j < U; ++j) p[j] = two_prod(ay[j], xs[j], e[j]);
+                fpe_absorb_prod<N, EE, U, GlobalSink, 1>(f1, p, e, s1);
+            }
+        }
+        for (; k < kend; ++k, col += lda) {
             const d2_t r = ld2<true>((const d2_t *)col);
             const double xv = xa[k];
             double p[1], e[1];
@@ -432,7 +460,7 @@ static hipError_t gemvN_fpe(Ctx &c, int m, int n, double alpha, const double *a,
         // the LDS-staged kernel below (variant 6) in one process: 1.40-1.45 ms against 1.41-1.48 at 32768^2
         hipLaunchKernelGGL(k_scale_x, dim3((n + 255) / 256), dim3(256), 0, st, n, alpha, x, (long long)incx, xa);
         hipLaunchKernelGGL((k_gemvN_fpe_sx<N, EE, 8>), grid, dim3(GV_BLOCK), 0, st, m, n, a, (long long)lda, xa, kper, part,
-                           ws, c.variant == 9 ? 0 : 1);
+                           ws, c.variant == 9 ? 0 : (c.variant == 10 ? 1 : 2));
     } else if (vec && c.variant == 1)
         hipLaunchKernelGGL((k_gemvN_fpe<N, EE, true, 4>), grid, dim3(GV_BLOCK), 0, st, m, n, alpha, a, (long long)lda, x,
                            (long long)incx, kper, part, ws);
