@@ -26,7 +26,6 @@
 #include <cstdint>
 #include <cstring>
 #include <mutex>
-#include <vector>
 
 namespace exb {
 
