@@ -575,7 +575,11 @@ def main():
                               "mfma_issued_Tops": issued, "mfma_issue_peak_Tops": peak_issue * world,
                               "mfma_util": issued / (peak_issue * world),
                               "traffic": load_traffic(args.traffic_json, GEMM_KERNEL.get(gm.get("path"), "k_gemm")),
-                              "kernel": GEMM_KERNEL.get(gm.get("path"), "k_gemm")}
+                              "kernel": GEMM_KERNEL.get(gm.get("path"), "k_gemm"),
+                              "note": "frac = frac_2mnk: algorithmic 2mnk flop / time / fp64 matrix peak (SURVEY 8(d)); it "
+                                      "can exceed 1 because the exact product runs on the int8 matrix cores (residues "
+                                      "modulo 8-bit moduli: products_per_pair int8 GEMMs); mfma_util = issued int8 "
+                                      "multiply-adds / the int8 peak"}
             out["exgemv"] = gv
             out["exgemm"] = gm
             out["extrsv"] = blas23["extrsv"]
