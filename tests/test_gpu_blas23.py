@@ -175,6 +175,41 @@ def test_exgemm_residue_path_is_exact(ex, oracle, m, n, k):
         lib.exblas_set_round_mode(0)
 
 
+@pytest.mark.parametrize("ta,tb,m,n,k", [("N", "N", 1000, 777, 2500), ("T", "N", 515, 1300, 900), ("N", "T", 700, 260, 20000)])
+def test_exgemm_residue_vs_digits_midsize(ex, oracle, ta, tb, m, n, k):
+    """Ragged mid-size products (several 256 x 256 workgroup tiles with clamped edges, k across the 8192-per-launch
+    boundary): the residue path, the digit-slice path and the scalar kernel produce the same bits, and a block of rows
+    equals the oracle."""
+    import torch
+    lib = ex.load_library()
+    lda = (m if ta == "T" else k) + 3
+    ldb = (k if tb == "T" else n) + 1
+    A = ex.gen_dev("fpuniform_signed", (k if ta == "T" else m) * lda, 71, 12, 6)
+    B = ex.gen_dev("lognormal", (n if tb == "T" else k) * ldb, 72, 0.0, 2.0)
+    C0 = ex.gen_dev("fpuniform_signed", m * n, 73, 10, 5)
+    outs = {}
+    try:
+        for path in (4, 2, 1):
+            lib.exblas_set_gemm_path(path)
+            C = C0.clone()
+            ex.exgemm_dev(ta, tb, m, n, k, -0.75, A, lda, B, ldb, 2.0, C, n, 8, True)
+            torch.cuda.synchronize()
+            assert gemm_info(lib)[0] == {4: 4, 2: 2, 1: 0}[path]
+            outs[path] = C
+    finally:
+        lib.exblas_set_gemm_path(0)
+    assert torch.equal(outs[4].view(torch.int64), outs[2].view(torch.int64)), "residues != digit slices"
+    assert torch.equal(outs[4].view(torch.int64), outs[1].view(torch.int64)), "residues != scalar kernel"
+    rows = 24                                    # the oracle on the first rows (full k)
+    ha, hb, hc0 = A.cpu().numpy(), B.cpu().numpy(), C0.cpu().numpy()
+    if ta == "T":
+        a_blk = np.ascontiguousarray(ha.reshape(k, lda)[:, :rows]).reshape(-1)
+        want = oracle.exgemm(ta, tb, rows, n, k, -0.75, a_blk, rows, hb, ldb, 2.0, hc0[:rows * n].copy(), n, 0)
+    else:
+        want = oracle.exgemm(ta, tb, rows, n, k, -0.75, ha[:rows * lda], lda, hb, ldb, 2.0, hc0[:rows * n].copy(), n, 0)
+    assert (_bits(outs[4].cpu().numpy()[:rows * n]) == _bits(want)).all()
+
+
 def test_exgemm_residue_path_long_k_and_capacity(ex, oracle):
     """k > 8192 (one contraction launch per 8192, residues added modulo p), k = 1, and the capacity knob: with fewer
     moduli reserved than the data needs the scalar kernel does the work -- same bits."""
