@@ -371,3 +371,17 @@ def test_host_api_spreads_over_virtual_devices(ex, oracle):
         assert lib.exblas_set_host_devices(1, (C.c_int * 1)(7)) != 0     # no such device on this box
     finally:
         lib.exblas_set_host_devices(0, None)
+
+
+def test_blas1_randomized_soak(ex):
+    """tools/stress_blas1.py: 150 random ExSUM / ExDOT cases -- lengths from 1 to 12M (below and above the capped, odd
+    grids; ragged tails), strides, misaligned offsets, every (fpe, early_exit) variant, independently chosen operand
+    families, occasional Inf / NaN / huge / subnormal entries: limbs and rounded value equal to the oracle's (a 2000-case
+    run of the same tool: profiles/r02_stress_blas1_2000.log)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_blas1.py"), "150", "5"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "0 mismatches" in r.stdout, (r.stdout[-3000:], r.stderr[-2000:])

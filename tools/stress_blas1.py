@@ -1,0 +1,83 @@
+"""Randomised soak of ExSUM / ExDOT against the oracle: python tools/stress_blas1.py [iterations] [seed].
+Random lengths (1 .. 12M: below and above the point where the grids are capped and made odd, ragged tails), strides,
+offsets (16-byte misalignment), every (fpe, early_exit) variant, operand families chosen independently, now and then
+an Inf / NaN / huge / subnormal entry; the 41 canonical limbs and the rounded double must equal the oracle's
+(host-pointer record calls: exblas_exsum_record / exblas_exdot_record, i.e. also the chunked multi-"device" host layer
+for the long vectors)."""
+import os
+import sys
+import time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch  # noqa: F401
+import exblas_amd as ex
+from oracle import pyoracle as o
+
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+ex.load_library().exblas_hip_init(-1)
+families = [("ill_cond", 1e32, 0), ("ill_cond", 1e8, 0), ("lognormal", 0.0, 2.0), ("lognormal", 0.0, 50.0),
+            ("fpuniform_signed", 40, 20), ("fpuniform_signed", 600, 300), ("fpuniform_signed", 1800, 900),
+            ("naive", 0, 0), ("fpuniform", 10, 0)]
+variants = [(0, False), (2, False), (3, False), (4, False), (5, False), (8, False), (12, False), (4, True), (6, True),
+            (8, True)]
+
+
+def same(x, y):
+    return (np.float64(x).view(np.int64) == np.float64(y).view(np.int64)) or (np.isnan(x) and np.isnan(y))
+
+
+t0 = time.time()
+bad = 0
+for it in range(iters):
+    r = rng.random()
+    n = int(rng.integers(1, 3000)) if r < 0.3 else (int(rng.integers(3000, 300000)) if r < 0.75 else
+                                                    int(rng.integers(1 << 20, 12 << 20)))
+    inca, incb = int(rng.choice([1, 1, 1, 2, 3, 5])), int(rng.choice([1, 1, 1, 2, 3]))
+    if n > (1 << 20):
+        inca = incb = int(rng.choice([1, 1, 2]))
+    offa, offb = int(rng.integers(0, 4)), int(rng.integers(0, 4))
+    fa, fb = families[int(rng.integers(0, len(families)))], families[int(rng.integers(0, len(families)))]
+    seed = int(rng.integers(1, 1 << 30))
+    a = o.gen(fa[0], offa + n * inca, seed, fa[1], fa[2])
+    b = o.gen(fb[0], offb + n * incb, seed + 1, fb[1], fb[2])
+    special = ""
+    q = rng.random()
+    if q < 0.05:
+        a[offa + inca * int(rng.integers(0, n))] = float(rng.choice([np.inf, -np.inf, np.nan]))
+        special = " +nonfinite"
+    elif q < 0.10:
+        a[offa + inca * int(rng.integers(0, n))] = 5e-324 * float(rng.integers(1, 1000))
+        special = " +subnormal"
+    elif q < 0.15:
+        a[offa + inca * int(rng.integers(0, n))] = float(rng.choice([1.0, -1.0])) * 2.0 ** float(rng.integers(1000, 1024))
+        special = " +huge"
+    fpe, ee = variants[int(rng.integers(0, len(variants)))]
+    do_dot = rng.random() < 0.5 and fa[0] != "fpuniform_signed" or (fa[1] < 1000 if fa[0] == "fpuniform_signed" else False)
+    desc = f"n={n} inc={inca},{incb} off={offa},{offb} A={fa} B={fb}{special} fpe={fpe}{'ee' if ee else ''}"
+    want_r, want_l = o.exsum(a, 0, inca=inca, offset=offa, n=n, limbs=True)
+    rec = ex.exsum_record(n, a, inca, offa, fpe, ee)
+    view = a[offa:offa + n * inca:inca]
+    finite = np.isfinite(view).all()
+    if not finite:
+        # the oracle (like the reference) defines nothing for Inf / NaN; the library answers as IEEE addition would:
+        # NaN if there is a NaN or infinities of both signs, else the infinity
+        has_nan, pinf, ninf = np.isnan(view).any(), (view == np.inf).any(), (view == -np.inf).any()
+        want_r = np.nan if (has_nan or (pinf and ninf)) else (np.inf if pinf else -np.inf)
+    ok = same(rec.exact, want_r) and (not finite or (rec.canon == want_l).all())
+    if not ok:
+        bad += 1
+        print(f"MISMATCH exsum it={it} {desc}: {rec.exact!r} vs {want_r!r}", flush=True)
+    if do_dot:
+        with np.errstate(all="ignore"):
+            prod_finite = np.isfinite(a[offa:offa + n * inca:inca] * b[offb:offb + n * incb:incb]).all()
+        if prod_finite and finite:  # the oracle (like the reference) defines nothing for overflowing products
+            want_r, want_l = o.exdot(a, b, 0, inca=inca, offa=offa, incb=incb, offb=offb, n=n, limbs=True)
+            rec = ex.exdot_record(n, a, inca, offa, b, incb, offb, fpe, ee)
+            if not (same(rec.exact, want_r) and (rec.canon == want_l).all()):
+                bad += 1
+                print(f"MISMATCH exdot it={it} {desc}: {rec.exact!r} vs {want_r!r}", flush=True)
+    if it % 50 == 0:
+        print(f"it {it}: {desc} [{time.time() - t0:.0f} s]", flush=True)
+print(f"done: {iters} cases, {bad} mismatches, {time.time() - t0:.0f} s")
+sys.exit(1 if bad else 0)
