@@ -31,7 +31,7 @@ C_ABI_SYMBOLS = [
     "exblas_exsum_accumulate_dev", "exblas_exdot_accumulate_dev", "exblas_finish_dev", "exblas_set_tuning",
     "exblas_set_gemm_path", "exblas_last_gemm_slices", "exblas_exsum_segmented_dev",
     "exblas_set_accumulator_slot", "exblas_stream_read2_dev", "exblas_extrsv_dev", "exblas_extrsv",
-    "exblas_extrsv_last_slow_rows", "exblas_reserve_workspace", "exblas_release_retired_workspaces",
+    "exblas_extrsv_last_slow_rows", "exblas_reserve_workspace", "exblas_release_retired_workspaces", "exblas_release_workspace",
     "exblas_comm_unique_id", "exblas_comm_init_rccl", "exblas_comm_adopt_rccl", "exblas_comm_init_host",
     "exblas_comm_destroy", "exblas_comm_rank", "exblas_comm_size", "exblas_shard_range",
     "exblas_exsum_allreduce_dev", "exblas_exdot_allreduce_dev", "exblas_allreduce_finish_dev",

@@ -380,16 +380,16 @@ __global__ void __launch_bounds__(256, 1) k_gemm_crt(int n, int row_end, int ty0
                                                      int kc0, int kc1, const signed char *__restrict__ PA,
                                                      const signed char *__restrict__ PB,
                                                      size_t plane_a, size_t plane_b, const int *__restrict__ info,
-                                                     unsigned *__restrict__ R, int m4)
+                                                     unsigned *__restrict__ R, int m4, int mod0)
 {
     __shared__ v4i_t lds[3][8 * 256];
     if (info[INFO_PATH] != PATH_CRT) return;
     const int L = info[INFO_CRT_L];
     const int by_cnt = (ty_cnt + 3) >> 2, bx_cnt = (gx + 3) >> 2, ntiles = by_cnt * bx_cnt;
-    const int mod = blockIdx.x / ntiles;
+    const int mod = mod0 + blockIdx.x / ntiles;
     if (mod >= L) return;
     int by, bx;
-    tile_of_block(blockIdx.x - mod * ntiles, ntiles, by_cnt, bx_cnt, &by, &bx);
+    tile_of_block(blockIdx.x % ntiles, ntiles, by_cnt, bx_cnt, &by, &bx);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wy = wave >> 1, wx = wave & 1, half = lane >> 5;
     const int p = g_crt.p[mod];
     const float invp = g_crt.invp[mod];
@@ -738,6 +738,9 @@ hipError_t exgemm_crt_prepare(Ctx &c, char transa, char transb, int m, int n, in
     plan->info = info; plan->EA = EA; plan->EB = EB; plan->PA = PA; plan->PB = PB;
     plan->R = (unsigned *)(base + o_r);
     plan->plane_a = plane_a; plan->plane_b = plane_b; plan->lcap = lcap; plan->m4 = m4;
+    // tuning variants 21..25: 1, 2, 3, 6 moduli per launch / all in one; default: by the number of tiles (exgemm_crt_rows)
+    plan->mods_per_launch = c.variant == 21 ? 1 : (c.variant == 22 ? 2 : (c.variant == 23 ? 3 : (c.variant == 24 ? 6 : (c.variant == 25 ? lcap : 0))));
+    plan->num_cu = c.num_cu;
     plan->beta = beta; plan->c = cmat; plan->ldc = ldc; plan->round_mode = round_mode;
     c.gemm_info_dev = info;
     return hipGetLastError();
@@ -750,10 +753,23 @@ hipError_t exgemm_crt_rows(const I8Plan &p, int row0, int row1, hipStream_t st)
     const int gy = (p.m + I8_T - 1) / I8_T, gx = (p.n + I8_T - 1) / I8_T;
     const int ty0 = row0 / I8_T, ty_cnt = (row1 - row0 + I8_T - 1) / I8_T;
     const int by_cnt = (ty_cnt + 3) / 4, bx_cnt = (gx + 3) / 4;
+    // A few moduli per launch (three at 8192^2).  The workgroups of an XCD share their A / B tile streams through its L2 only while they
+    // run in step; they start in step at the beginning of a launch and drift apart afterwards (12 rounds of 256 workgroups
+    // per launch here, 72 with all 18 moduli in one launch): 15 GB through the fabric per 8192^3 call against 30.5 GB,
+    // 11.3 ms against 11.5 (1 per launch: 14.5 GB, 11.4 ms).  Launches for moduli the data does not need exit at once.
+    // In general: about 12 rounds of one workgroup per CU per launch.
+    int per = p.mods_per_launch;
+    if (per <= 0) {
+        const long long tiles = (long long)by_cnt * bx_cnt;
+        per = (int)max(1ll, min((long long)p.lcap, (12ll * p.num_cu) / max(1ll, tiles)));
+    }
     for (int kc0 = 0; kc0 < p.KC; kc0 += CRT_KPASS)
-        hipLaunchKernelGGL(k_gemm_crt, dim3((unsigned)(p.lcap * by_cnt * bx_cnt)), dim3(256), 0, st, p.n, row1, ty0, ty_cnt,
-                           gy, gx, p.KC, kc0, min(p.KC, kc0 + CRT_KPASS), p.PA, p.PB, p.plane_a, p.plane_b, p.info, p.R,
-                           p.m4);
+        for (int mod0 = 0; mod0 < p.lcap; mod0 += per) {
+            const int nm = min(per, p.lcap - mod0);
+            hipLaunchKernelGGL(k_gemm_crt, dim3((unsigned)(nm * by_cnt * bx_cnt)), dim3(256), 0, st, p.n, row1, ty0, ty_cnt,
+                               gy, gx, p.KC, kc0, min(p.KC, kc0 + CRT_KPASS), p.PA, p.PB, p.plane_a, p.plane_b, p.info, p.R,
+                               p.m4, mod0);
+        }
     const long long groups = (row1 - row0 + 3) / 4;
 #define CRT_FIN(WIDE, ALL)                                                                                               \
     hipLaunchKernelGGL((k_crt_finish<WIDE>), dim3((unsigned)((groups * p.n + 255) / 256)), dim3(256), 0, st, row0, row1,  \

@@ -591,6 +591,28 @@ int exblas_release_retired_workspaces(void)
     return (int)first;
 }
 
+int exblas_release_workspace(void)
+{
+    ctx(-1);
+    hipError_t first = hipDeviceSynchronize();
+    for_each_layer(current_device(), [&](Ctx &c) {
+        std::lock_guard<std::mutex> lk(c.mu);
+        for (void *p : c.retired) {
+            hipError_t e = hipFree(p);
+            if (first == hipSuccess) first = e;
+        }
+        c.retired.clear();
+        if (c.ws) {
+            hipError_t e = hipFree(c.ws);
+            if (first == hipSuccess) first = e;
+        }
+        c.ws = nullptr;
+        c.ws_bytes = 0;
+        c.gemm_info_dev = nullptr;  // it pointed into the workspace
+    });
+    return (int)first;
+}
+
 int exblas_gen_dev(int kind, uint64_t seed, int64_t first, int64_t count, int64_t n_total, double p0, double p1,
                    double *d_out, void *stream)
 {

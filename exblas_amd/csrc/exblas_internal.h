@@ -105,7 +105,7 @@ struct I8Plan {
     bool crt = false;
     unsigned *R = nullptr;
     size_t plane_a = 0, plane_b = 0;
-    int lcap = 0, m4 = 0;
+    int lcap = 0, m4 = 0, mods_per_launch = 0, num_cu = 256;
     double beta = 0.0;
     double *c = nullptr;
     int ldc = 0, round_mode = 0;

@@ -102,6 +102,9 @@ int exblas_reserve_workspace(size_t bytes);
 /* Frees the workspace blocks that later, larger calls replaced.  Synchronises the device; only call it when no graph
  * captured before the growth will be replayed again. */
 int exblas_release_retired_workspaces(void);
+/* Frees the current workspace as well (a large exgemm leaves gigabytes reserved: 39 bytes per entry of A, B and
+ * 4-row group of C for the residue path).  Synchronises the device; graphs captured so far must not be replayed. */
+int exblas_release_workspace(void);
 /* 0 = exact, 1 = reference; overrides EXBLAS_ROUND for the host-pointer API */
 void exblas_set_round_mode(int mode);
 int exblas_get_round_mode(void);

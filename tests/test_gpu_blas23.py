@@ -387,7 +387,8 @@ def test_exgemm_is_stream_ordered_and_capturable(ex, oracle):
     big = 1024
     Ab = ex.gen_dev("fpuniform", big * big, 53, 10, 0)
     Cb = torch.zeros(big * big, dtype=torch.float64, device="cuda")
-    lib.exblas_release_retired_workspaces()
+    del g, g3                                    # the graphs captured above die with the workspace they point into
+    assert lib.exblas_release_workspace() == 0   # whatever earlier tests left reserved: the next call has to allocate
     g2 = torch.cuda.CUDAGraph()
     with pytest.raises(RuntimeError):
         with torch.cuda.stream(s):
