@@ -45,6 +45,7 @@ def short(name):
 
 
 PREDICATED = {"k_gemm_i8", "k_gemm", "k_i8_finish", "k_i8_zero_w", "k_crt_finish"}
+PER_CALL = {"k_gemm_crt": "k_crt_decide"}
 means = collections.defaultdict(dict)
 for which, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     f = one(f"{which}/*/*_counter_collection.csv")
@@ -60,6 +61,12 @@ for which, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE"))
         # block, k block) pass, exiting at once when the device-side decision does not need that pass; k_exsum on the
         # 2^28-element vectors AND on the 64 MiB chunks of the host-pointer call.  For those the figure wanted is the
         # full-size launch: the mean over the launches within 5 % of the largest.
+        if k in PER_CALL and acc.get(PER_CALL[k]):
+            # a kernel launched several times per library call (k_gemm_crt: a few moduli per launch, launches beyond
+            # the data's modulus count exit at once): the figure wanted is the sum over one CALL = total / number of
+            # launches of the once-per-call kernel named in PER_CALL
+            means[k][counter] = sum(v) / len(acc[PER_CALL[k]])
+            continue
         if k in PREDICATED or k in ("k_exsum", "k_exdot"):
             top = max(v)
             v = [t for t in v if t >= 0.95 * top]
@@ -78,8 +85,9 @@ if f:
         fh.write("kernel,launches," + ",".join(counters) + "\n")
         for k, d in sorted(acc.items()):
             def full_size(vals):
-                # see the note at PREDICATED: only the launches that did the full-size work
-                if short(k + "(") in PREDICATED or short(k + "(") in ("k_exsum", "k_exdot"):
+                # see the note at PREDICATED: only the launches that did the full-size work (k_gemm_crt: the launches
+                # with all their moduli in use)
+                if short(k + "(") in PREDICATED or short(k + "(") in ("k_exsum", "k_exdot", "k_gemm_crt"):
                     top = max(vals)
                     vals = [t for t in vals if t >= 0.95 * top] if top > 0 else vals
                 return vals
