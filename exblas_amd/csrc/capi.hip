@@ -96,7 +96,7 @@ Ctx &ctx(int device, int layer)
         c.num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         c.blocks_per_cu = env_int("EXBLAS_BLOCKS_PER_CU", 8);
         c.bpc_sum = env_int("EXBLAS_BPC_SUM", 2);
-        c.bpc_dot = env_int("EXBLAS_BPC_DOT", 32);
+        c.bpc_dot = env_int("EXBLAS_BPC_DOT", 48);
         c.bpc_sa = env_int("EXBLAS_BPC_SA", 3);
         c.bpc_heavy = env_int("EXBLAS_BPC_HEAVY", 4);
         c.ngroups = env_int("EXBLAS_NGROUPS", 32);

@@ -16,7 +16,7 @@ struct Ctx {
     int blocks_per_cu = 8;   // EXBLAS_BLOCKS_PER_CU: generic cap of resident blocks per CU
     // Measured on MI355X (tools/tune.py, n = 2^28): the one-stream ExSUM kernel is fastest with FEW fat
     // blocks (2 per CU: 7.15 TB/s vs 6.46 at 8), the two-stream ExDOT kernel with many (16-32 per CU).
-    int bpc_sum = 2, bpc_dot = 32;
+    int bpc_sum = 2, bpc_dot = 48;   // ExDOT: 48 (an odd grid of 12289 workgroups) edges out 32 by ~1 %, 16 and 96 lose 2-3 %
     int bpc_sa = 3;          // superaccumulator-only ExSUM (LDS-atomic bound; 3/CU: 6.65 TB/s, 2/CU: 6.0)
     int bpc_heavy = 4;       // ExSUM variants without early exit, N >= 5 (VALU-latency-bound)
     int ngroups = 32;        // EXBLAS_NGROUPS: global group accumulators the blocks add into
