@@ -336,7 +336,7 @@ __device__ __forceinline__ void crt_residues_body(const double *__restrict__ src
 #pragma unroll
             for (int j = 0; j < NW; ++j) s = __builtin_amdgcn_udot4(w[j][e], c[j], s, false);
             const unsigned q = (unsigned)((float)s * invp);  // s < 2^20: exact float; q = floor(s/p) or one less
-            unsigned rr = s - q * p;
+            unsigned rr = s - __umul24(q, p);                // q < 2^15, p <= 256: the full-rate 24-bit multiply
             rr = min(rr, rr - p);                            // rr >= p  ->  rr - p (unsigned wrap otherwise)
             int sv = (int)rr - (rr > hi ? (int)p : 0);       // symmetric residue in [-(p-1)/2 .. (p-1)/2], p = 256: [-128, 127]
             sv = ((negmask >> e) & 1u) ? -sv : sv;           // p = 256: -(-128) wraps to -128 = 128 mod 256
@@ -500,7 +500,7 @@ __global__ void __launch_bounds__(256, 1) k_gemm_crt(int n, int row_end, int ty0
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
                     const int a = acc[pu * 4 + qu][4 * a4 + b];
-                    int rr = a - (int)floorf((float)a * invp) * p;  // quotient off by at most one either way
+                    int rr = a - __mul24((int)floorf((float)a * invp), p);  // |q| < 2^22; off by at most one either way
                     rr = rr < 0 ? rr + p : rr;
                     rr = rr >= p ? rr - p : rr;
                     word |= (unsigned)rr << (8 * b);
