@@ -5,13 +5,26 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path over one of the rank's synthetic vectors: the streaming kernel, the finalize
+With --gpus N > 1 and no WORLD_SIZE in the environment the script launches its own N ranks (a child
+`python -m torch.distributed.run ...` started before this process touches a GPU), relays rank 0's JSON line and exits
+with the child's status; it refuses (exit 2) when the box has fewer than N devices.  It never degrades to fewer ranks.
+
+A "step" is one pass of the hot path over one of the synthetic vectors: the streaming kernel, the finalize
 kernel and -- for N > 1 -- the 576-byte int64 all-reduce of the digit set plus the re-finalize, all issued by
 libexblas.so (exblas_exsum_accumulate_dev + exblas_allreduce_finish_dev: ncclAllReduce on a HIP stream, no
-torch.distributed in the step).  Weak scaling: every rank holds --rotate (default 4) DISTINCT vectors of n elements
-(default 2^28 = 2 GiB each) and step i reads vector i mod rotate, so no step can be served by the 256 MiB Infinity
-Cache from the previous one; `value` = N*n*K / max-over-ranks time.  The same-buffer variant (every step re-reads one
-vector) is measured beside it and reported under roofline.same_buffer.
+torch.distributed in the step).  --rotate (default 4) DISTINCT vectors are cycled through, so no step can be served by
+the 256 MiB Infinity Cache from the previous one.  The same-buffer variant (every step re-reads one vector) is measured
+beside it and reported under roofline.same_buffer.
+
+Scaling (BASELINE config 3; reference: ONE vector scattered over the ranks, limbs reduced, root rounds --
+src/cpu/blas/blas1/ExSUM.cpp:33-63,142-152):
+  * N == 1: the vector has n = 2^log2n elements.
+  * N > 1, --scaling strong (default): the SAME vectors of n_total = 2^log2n elements, rank r holding the contiguous
+    shard exblas_shard_range(n_total, r, N) of each; `value` = n_total*K / max-over-ranks time; `result_bits` (the 8
+    bytes of the rounded result) and `limbs_crc` are therefore comparable across N, and rank 0 re-computes the full
+    vector on the CPU (`bit_exact_vs_cpu`).  The weak-scaling figure (2^log2n elements PER GPU) is measured beside it
+    and reported under "weak".
+  * --scaling weak makes the weak figure the headline (n_total = N * 2^log2n).
 
 Prints ONE JSON line on rank 0 (see README / task contract), with `roofline` for the dominant kernel (k_exsum resp.
 k_exdot: algorithmic 8 resp. 16 B/element over the HIP-event time of that kernel alone) and `cpu_baseline` (N == 1
@@ -41,7 +54,11 @@ def parse():
                     help="untimed clock ramp-up before the W warmup steps: the same kernel run back to back "
                          "(the chip needs a few hundred ms of load to reach its sustained clocks)")
     ap.add_argument("--op", default="exsum", choices=["exsum", "exdot"])
-    ap.add_argument("--log2n", type=int, default=28, help="elements per GPU and vector = 2^log2n")
+    ap.add_argument("--log2n", type=int, default=28, help="elements per vector = 2^log2n (per GPU for weak scaling)")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="N > 1: strong = ONE vector of 2^log2n elements partitioned n/N (BASELINE config 3, bits "
+                         "comparable across N); weak = 2^log2n elements per GPU")
+    ap.add_argument("--no-weak-leg", action="store_true", help="N > 1, strong: skip the secondary weak-scaling figure")
     ap.add_argument("--rotate", type=int, default=4, help="distinct input vectors the steps cycle through")
     ap.add_argument("--kind", default="ill_cond")
     ap.add_argument("--p0", type=float, default=1e32)
@@ -50,6 +67,7 @@ def parse():
     ap.add_argument("--no-early-exit", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary line items (ExDOT, BLAS2/3, host API)")
+    ap.add_argument("--skip-blas23", action="store_true", help="skip the ExGEMV / ExGEMM / ExTRSV line items")
     ap.add_argument("--no-host-api", action="store_true",
                     help="skip the host-pointer exsum() line item (its 64 MiB chunk launches of k_exsum would dilute the "
                          "per-kernel averages of a rocprofv3 --stats run)")
@@ -296,8 +314,10 @@ def probe_read(ex, torch, buffers, two_stream, n):
 
 def bench_blas23(ex, torch, comm, world, rank):
     """ExGEMV m=n=32768 'N' column-major per GPU (config 4; replicas for N > 1) and ExGEMM n=8192 row-sharded
-    over the ranks (config 5: each rank owns 8192/N rows of A and C; B broadcast and C all-gathered by
-    exblas_exgemm_sharded_dev when N > 1)."""
+    over the ranks (config 5: each rank owns 8192/N rows of A and C, B replicated; alpha = beta = 1 as in the
+    reference test, tests/test.exgemm.gpu.cpp:183-184).  N > 1 reports two timings: `ms` = the row-sharded product with
+    C left sharded (B already on every rank: no collective at all) and `ms_gathered` = B broadcast from rank 0 + the
+    product + in-place all-gather of C inside exblas_exgemm_sharded_dev."""
     def timeit(fn, reps):
         fn()
         torch.cuda.synchronize()
@@ -340,18 +360,41 @@ def bench_blas23(ex, torch, comm, world, rank):
     r0, r1 = ex.row_block(N, rank, world)
     A = ex.gen_dev("fpuniform", N * N, 14, 10.0, 0.0, first=r0 * N, count=(r1 - r0) * N)
     B = ex.gen_dev("fpuniform", N * N, 15, 10.0, 0.0)
-    C = torch.zeros(N * N, dtype=torch.float64, device="cuda")
+    C0 = ex.gen_dev("fpuniform", N * N, 18, 10.0, 0.0)
+    C = torch.empty_like(C0)
 
-    def gemm():
+    def gemm(gather):
         if comm is not None:
-            ex.exgemm_sharded(comm, N, N, N, 1.0, A, B, 0.0, C, 8, True, b_root=0)
+            ex.exgemm_sharded(comm, N, N, N, 1.0, A, B, 1.0, C, 8, True, b_root=0 if gather else -1, gather=gather)
         else:
-            ex.exgemm_dev("N", "N", N, N, N, 1.0, A, N, B, N, 0.0, C, N, 8, True)
-    ms = timeit(gemm, 3)
-    gm = {"workload": f"ExGEMM n=8192 fp64 row-major alpha=1 beta=0, rows sharded over {world} GPU(s)"
-                      + (", B broadcast + C all-gather inside the call" if comm is not None else ""),
+            ex.exgemm_dev("N", "N", N, N, N, 1.0, A, N, B, N, 1.0, C, N, 8, True)
+
+    def timed_gemm(gather, reps=3):
+        # beta = 1 updates C in place: every timed call starts from the same C0 (the copy is outside the events)
+        tot = 0.0
+        for it in range(reps + 1):
+            C.copy_(C0)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            gemm(gather)
+            e1.record()
+            torch.cuda.synchronize()
+            if it:
+                tot += e0.elapsed_time(e1)
+        return tot / reps
+    ms = timed_gemm(False)
+    gm = {"workload": f"ExGEMM n=8192 fp64 row-major alpha=beta=1 (tests/test.exgemm.gpu.cpp:183-184), rows of A and C "
+                      f"sharded over {world} GPU(s), B replicated" + (", C left sharded" if comm is not None else ""),
           "ms": ms, "flop_2mnk": 2.0 * N * N * N}
     gm.update(gemm_path_info(lib))
+    # checksum of the rank's rows of C (position-weighted, exact in int64 modular arithmetic): comparable across N
+    own = C.view(torch.int64)[r0 * N:r1 * N]
+    idx = torch.arange(r0 * N, r1 * N, device="cuda", dtype=torch.int64)
+    gm["c_checksum_local"] = int(((own ^ (idx * -7046029254386353131)) * 1099511628211 + idx).sum().item())
+    if comm is not None:
+        gm["ms_gathered"] = timed_gemm(True)
+        gm["gathered_note"] = "B broadcast from rank 0 + product + in-place all-gather of C inside the call"
     return {"exgemv": gv, "exgemm": gm, "extrsv": tv}
 
 
@@ -405,17 +448,102 @@ def bench_host_api(ex, torch, x_dev, fpe, ee):
             "same_bits_as_dev_path": bool(np.float64(val).view(np.int64) == np.float64(rec.value()).view(np.int64))}
 
 
+def launch_ranks(args):
+    """--gpus N > 1 without a launcher: start N fresh ranks as a CHILD process tree.  This process has not touched a
+    GPU (device_count() does not initialise the runtime) and never execs; it relays rank 0's JSON line."""
+    import socket
+    import subprocess
+    import torch
+    backend = os.environ.get("EXBLAS_BENCH_BACKEND", "nccl")
+    have = torch.cuda.device_count()
+    if backend == "nccl" and have < args.gpus:
+        print(f"[bench] --gpus {args.gpus} but only {have} HIP device(s) are visible: refusing to run with fewer ranks "
+              "(EXBLAS_BENCH_BACKEND=gloo rehearses N ranks on fewer devices through the host transport)",
+              file=sys.stderr, flush=True)
+        sys.exit(2)
+    if have < 1:
+        print("[bench] no HIP device visible; there is no CPU fallback", file=sys.stderr, flush=True)
+        sys.exit(2)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line = None
+    for ln in proc.stdout:
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln.strip()
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if rc != 0 or line is None:
+        print(f"[bench] the {args.gpus}-rank run failed (exit {rc}, JSON line {'present' if line else 'missing'})",
+              file=sys.stderr, flush=True)
+        sys.exit(rc or 1)
+    print(line, flush=True)
+    sys.exit(0)
+
+
+def record_ids(rec):
+    """the 8 bytes of the rounded result (both roundings) and a CRC of the 41 canonical limbs: equal across GPU counts"""
+    import struct
+    import zlib
+    import numpy as np
+    return {"result_bits": "0x%016x" % struct.unpack("<Q", struct.pack("<d", rec.exact))[0],
+            "result_bits_reference_rounding": "0x%016x" % struct.unpack("<Q", struct.pack("<d", rec.refmode))[0],
+            "limbs_crc": "0x%08x" % (zlib.crc32(np.ascontiguousarray(rec.canon, dtype="<i8").tobytes()) & 0xffffffff)}
+
+
+def cpu_parity_only(op, host_arrays, fpe, ee, rec_gpu):
+    """ONE run of the CPU core on the full vector(s) (all host threads): the bit check of an N > 1 run and of the ExDOT
+    leg; not a timing."""
+    import numpy as np
+    from oracle import pyoracle as O
+    nt = max(1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else host_cores())
+    use_ref = op == "exsum" and O.ref() is not None
+    t0 = time.perf_counter()
+    if use_ref:
+        val, limbs = O.ref_exsum(host_arrays[0], fpe, ee, nthreads=nt, limbs=True)
+    elif op == "exsum":
+        val, limbs = O.exsum_omp(host_arrays[0], fpe, ee, nt, limbs=True)
+    else:
+        val, limbs = O.exdot_omp(host_arrays[0], host_arrays[1], fpe, ee, nt, limbs=True)
+    dt = time.perf_counter() - t0
+    limbs = np.asarray(limbs)
+    same = lambda a, b: np.float64(a).view(np.int64) == np.float64(b).view(np.int64)  # noqa: E731
+    d = {"limbs_equal": bool((limbs == np.asarray(rec_gpu.canon)).all()),
+         "double_equal_exact_rounding": bool(same(O.round_limbs(limbs, O.ROUND_EXACT), rec_gpu.exact)),
+         "double_equal_reference_rounding": bool(same(O.round_limbs(limbs, O.ROUND_REFERENCE), rec_gpu.refmode)),
+         "cpu_core": ("oracle/_ref (reference FPExpansionVect+Superaccumulator, compiled)" if use_ref
+                      else "oracle/exblas_oracle.c OpenMP port"),
+         "cpu_threads": nt, "cpu_seconds": dt, "n": int(host_arrays[0].size)}
+    return bool(d["limbs_equal"] and d["double_equal_exact_rounding"] and d["double_equal_reference_rounding"]), d
+
+
 def main():
     args = parse()
-    import torch
-    import exblas_amd as ex
-
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        launch_ranks(args)          # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        # never run a different number of ranks than the line will claim
+        print(f"[bench] --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks", file=sys.stderr, flush=True)
+        sys.exit(2)
+
+    import torch
+    import exblas_amd as ex
+
     dist = None
     comm = None
-    transport = "native RCCL int64 all-reduce (ncclAllReduce issued by libexblas.so)"
+    transport = "none (single GPU)"
     force_dist = os.environ.get("EXBLAS_BENCH_FORCE_DIST") == "1"  # rehearse the RCCL path with a 1-rank communicator
     if world > 1:
         import torch.distributed as dist
@@ -426,8 +554,13 @@ def main():
         # share the devices round-robin and the library uses its host-callback transport).
         backend = os.environ.get("EXBLAS_BENCH_BACKEND", "nccl")
         if backend == "nccl":
+            if torch.cuda.device_count() < world:
+                print(f"[bench] rank {rank}: {world} ranks but {torch.cuda.device_count()} devices", file=sys.stderr,
+                      flush=True)
+                sys.exit(2)
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            transport = "native RCCL int64 all-reduce (ncclAllReduce issued by libexblas.so)"
         else:
             torch.cuda.set_device(local_rank % torch.cuda.device_count())
             dist.init_process_group(backend)
@@ -449,27 +582,52 @@ def main():
         elif comm is None:
             raise SystemExit("no communicator")
         else:
-            transport = "host-callback transport (gloo rehearsal)"
+            transport = "host-callback transport (gloo rehearsal, ranks may share a GPU)"
     else:
         torch.cuda.set_device(0)
         if force_dist:
             comm = ex.Comm.rccl(ex.Comm.unique_id(), 0, 1)
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    ex.load_library().exblas_hip_init(-1)
+            transport = "native RCCL, one-rank communicator (rehearsal)"
+    lib = ex.load_library()
+    lib.exblas_hip_init(-1)
+    n_ranks_seen = lib.exblas_comm_size(comm.handle) if comm is not None else 1
+    if world > 1 and n_ranks_seen != world:
+        print(f"[bench] communicator spans {n_ranks_seen} ranks, expected {world}", file=sys.stderr, flush=True)
+        sys.exit(2)
 
     n = 1 << args.log2n
-    n_total = n * world
     ee = not args.no_early_exit
-    first = rank * n
     nrot = max(1, args.rotate)
+    strong = world > 1 and args.scaling == "strong"
 
-    def make_buffers(op):
+    def make_buffers(op, mode):
+        """mode 'strong': the rank's shard of vectors of n elements in all; 'weak': n elements per rank of vectors of
+        n*world.  Seeds 1, 3, 5, ... (and 2, 4, ... for ExDOT's second operand) per rotating vector."""
+        if mode == "strong":
+            n_total = n
+            first, last = ex.shard_range(n_total, rank, world)
+        else:
+            n_total = n * world
+            first, last = rank * n, (rank + 1) * n
         out = []
         for j in range(nrot):
-            t = [ex.gen_dev(args.kind, n, 1 + 2 * j, args.p0, args.p1, first=first, count=n, n_total=n_total)]
+            t = [ex.gen_dev(args.kind, n_total, 1 + 2 * j, args.p0, args.p1, first=first, count=last - first,
+                            n_total=n_total)]
             if op == "exdot":
-                t.append(ex.gen_dev(args.kind, n, 2 + 2 * j, args.p0, args.p1, first=first, count=n, n_total=n_total))
+                t.append(ex.gen_dev(args.kind, n_total, 2 + 2 * j, args.p0, args.p1, first=first, count=last - first,
+                                    n_total=n_total))
             out.append(t)
+        return out, n_total, last - first
+
+    def full_host_vectors(op, n_total):
+        """rank 0: vector 0 (seed 1, and 2) in full on the host -- generated on the GPU, where the generator is
+        bit-identical to the oracle's (tests/), then copied"""
+        out = []
+        for seed in ((1, 2) if op == "exdot" else (1,)):
+            t = ex.gen_dev(args.kind, n_total, seed, args.p0, args.p1)
+            out.append(t.cpu().numpy())
+            del t
+        torch.cuda.empty_cache()
         return out
 
     def reduce_max(*vals):
@@ -479,81 +637,143 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return tuple(float(v) for v in t)
 
-    def run_op(op):
+    def run_op(op, mode, same_buffer=True, probes=True):
         """rotating (headline) and same-buffer timings + probes of one op; returns the JSON pieces"""
-        bufs = make_buffers(op)
+        bufs, n_total, n_local = make_buffers(op, mode)
         rec = ex.new_record_buffer()
         dt, kms = timed_steps(ex, torch, dist, comm, op, bufs, args.fpe, ee, args.steps, args.warmup, world, rec,
                               args.prewarm_ms)
         dt, kms = reduce_max(dt, kms)
-        rec1 = ex.new_record_buffer()
-        dt1, kms1 = timed_steps(ex, torch, dist, comm, op, bufs[:1], args.fpe, ee, args.steps, args.warmup, world,
-                                rec1, 0.0)
-        dt1, kms1 = reduce_max(dt1, kms1)
-        probe_rot, probe_same = probe_read(ex, torch, bufs, op == "exdot", n)
         bpe = 8 if op == "exsum" else 16
-        ach, ach1 = n * bpe / (kms * 1e-3) / 1e9, n * bpe / (kms1 * 1e-3) / 1e9
+        ach = n_local * bpe / (kms * 1e-3) / 1e9
         roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                "traffic": load_traffic(args.traffic_json, f"k_{op}"), "kernel": f"k_{op}", "kernel_ms": kms,
-                "rotating_buffers": nrot, "measured_read_probe_GBs": probe_rot, "frac_of_probe": ach / probe_rot,
-                "same_buffer": {"achieved": ach1, "frac": ach1 / HBM_PEAK_GBS, "kernel_ms": kms1,
-                                "ms_per_step": dt1 / args.steps * 1e3, "measured_read_probe_GBs": probe_same,
-                                "note": "every step re-reads ONE 2^log2n-element vector: up to 256 MiB of it can "
-                                        "come from the Infinity Cache"}}
-        # the record of the LAST step belongs to buffer (steps-1) mod rotate; buffer 0's result comes from rec1
-        return bufs, dt, roof, ex.read_record(rec1)
+                "traffic": load_traffic(args.traffic_json, f"k_{op}") if n_local == (1 << 28) else None,
+                "kernel": f"k_{op}", "kernel_ms": kms, "elements_per_launch": n_local, "rotating_buffers": nrot}
+        if world > 1:
+            roof["note"] = ("per GPU: the algorithmic bytes of the rank's shard / the slowest rank's mean kernel time; "
+                            "traffic counters are collected at N = 1 only")
+        result = None
+        if same_buffer:
+            rec1 = ex.new_record_buffer()
+            dt1, kms1 = timed_steps(ex, torch, dist, comm, op, bufs[:1], args.fpe, ee, args.steps, args.warmup, world,
+                                    rec1, 0.0)
+            dt1, kms1 = reduce_max(dt1, kms1)
+            ach1 = n_local * bpe / (kms1 * 1e-3) / 1e9
+            roof["same_buffer"] = {"achieved": ach1, "frac": ach1 / HBM_PEAK_GBS, "kernel_ms": kms1,
+                                   "ms_per_step": dt1 / args.steps * 1e3,
+                                   "note": "every step re-reads ONE vector: up to 256 MiB of it can come from the "
+                                           "Infinity Cache"}
+            # the record of the LAST rotating step belongs to buffer (steps-1) mod rotate; buffer 0's result is rec1
+            result = ex.read_record(rec1)
+        if probes:
+            probe_rot, probe_same = probe_read(ex, torch, bufs, op == "exdot", n_local)
+            roof["measured_read_probe_GBs"] = probe_rot
+            roof["frac_of_probe"] = ach / probe_rot
+            if same_buffer:
+                roof["same_buffer"]["measured_read_probe_GBs"] = probe_same
+        return bufs, dt, roof, result, n_total
 
-    bufs, dt, roof, result = run_op(args.op)
-    x0 = bufs[0]
+    def leg(op, want_cpu_timing):
+        """the headline measurement of one op in the selected scaling mode (+ the weak figure beside a strong one,
+        + the CPU bit check); returns (JSON pieces, device vector 0 for the host-API item)"""
+        mode = "strong" if strong else "weak"
+        bufs, dt, roof, result, n_total = run_op(op, mode)
+        o = {"value": n_total * args.steps / dt / 1e9, "unit": "Gelem/s", "ms_per_step": dt / args.steps * 1e3,
+             "scaling": "strong" if strong else "weak", "n_total": n_total, "roofline": roof,
+             "result": result.exact}
+        o.update(record_ids(result))
+        keep = bufs[0][0] if world == 1 else None
+        host0 = None
+        if world == 1 and not args.no_cpu_baseline:
+            host0 = [t.cpu().numpy() for t in bufs[0]]
+        del bufs
+        torch.cuda.empty_cache()
+        if strong and not args.no_weak_leg:
+            wb, wdt, wroof, _, wn = run_op(op, "weak", same_buffer=False, probes=False)
+            o["weak"] = {"value": wn * args.steps / wdt / 1e9, "unit": "Gelem/s", "ms_per_step": wdt / args.steps * 1e3,
+                         "scaling": "weak", "elements_per_gpu": n, "n_total": wn, "kernel_ms": wroof["kernel_ms"],
+                         "frac_hbm_peak_per_gpu": wroof["frac"]}
+            del wb
+            torch.cuda.empty_cache()
+        if not args.no_cpu_baseline and rank == 0:
+            if world > 1:
+                host0 = full_host_vectors(op, n_total)
+            if want_cpu_timing and world == 1:
+                base, parity = cpu_baseline(op, host0, args.fpe, ee, result)
+                o["cpu_baseline"] = base
+                o["bit_exact_vs_cpu"] = bool(parity["limbs_equal"] and parity["double_equal_exact_rounding"] and
+                                             parity["double_equal_reference_rounding"])
+                o["bit_exact_detail"] = parity
+            else:
+                o["bit_exact_vs_cpu"], o["bit_exact_detail"] = cpu_parity_only(op, host0, args.fpe, ee, result)
+        host0 = None
+        if world > 1:
+            dist.barrier()      # the other ranks wait for rank 0's CPU run
+        return o, keep
+
+    head, keep = leg(args.op, True)
 
     secondary = None
     blas23 = None
     host_api = None
     if not args.no_secondary and args.op == "exsum":
-        host0 = [t.cpu().numpy() for t in x0] if (world == 1 and not args.no_cpu_baseline) else None
-        keep = x0[0]
-        del bufs
-        torch.cuda.empty_cache()
-        # ExDOT on the same shape (BASELINE config 2), reported beside the headline number
-        dbufs, ddt, droof, dres = run_op("exdot")
-        secondary = {"metric": "ExDOT fp64 Gelem/s", "value": n_total * args.steps / ddt / 1e9, "unit": "Gelem/s",
-                     "ms_per_step": ddt / args.steps * 1e3, "roofline": droof, "result": dres.exact}
-        del dbufs
-        torch.cuda.empty_cache()
+        # ExDOT on the same shape (BASELINE config 3), reported beside the headline number
+        secondary, _ = leg("exdot", False)
+        secondary["metric"] = "ExDOT fp64 Gelem/s"
         # BASELINE configs 4 and 5 on the same box (kernel-chain time by HIP events; parity is covered by tests/)
-        blas23 = bench_blas23(ex, torch, comm, world, rank)
-        if world > 1:
-            gvm, gmm = reduce_max(blas23["exgemv"]["ms"], blas23["exgemm"]["ms"])
-            blas23["exgemv"]["ms"], blas23["exgemm"]["ms"] = gvm, gmm
+        if not args.skip_blas23:
+            blas23 = bench_blas23(ex, torch, comm, world, rank)
+        if blas23 and world > 1:
+            gm = blas23["exgemm"]
+            gvm, gmm, gmg = reduce_max(blas23["exgemv"]["ms"], gm["ms"], gm.get("ms_gathered", 0.0))
+            blas23["exgemv"]["ms"], gm["ms"], gm["ms_gathered"] = gvm, gmm, gmg
+            ck = torch.tensor([gm["c_checksum_local"]], dtype=torch.int64, device="cuda")
+            dist.all_reduce(ck, op=dist.ReduceOp.SUM)
+            gm["c_checksum"] = "0x%016x" % (int(ck.item()) & 0xffffffffffffffff)
+        elif blas23:
+            blas23["exgemm"]["c_checksum"] = "0x%016x" % (blas23["exgemm"]["c_checksum_local"] & 0xffffffffffffffff)
+        if blas23:
+            del blas23["exgemm"]["c_checksum_local"]
         if world == 1 and not args.no_host_api:
             host_api = bench_host_api(ex, torch, keep, args.fpe, ee)
-    else:
-        host0 = [t.cpu().numpy() for t in x0] if (world == 1 and not args.no_cpu_baseline) else None
+    del keep
 
     if rank == 0:
+        opname = f"Ex{args.op[2:].upper()}"
+        if world == 1:
+            shape = f"n=2^{args.log2n}"
+            par = "single"
+        elif strong:
+            shape = f"ONE vector of n=2^{args.log2n} partitioned n/{world} (exblas_shard_range)"
+            par = f"shard{world} of one vector, 576-byte digit set all-reduced per step"
+        else:
+            shape = f"n=2^{args.log2n} per GPU ({world}*2^{args.log2n} in all)"
+            par = f"shard{world}, 2^{args.log2n} elements per GPU, 576-byte digit set all-reduced per step"
         out = {
-            "metric": f"Ex{args.op[2:].upper()} fp64 Gelem/s at n=2^{args.log2n} per GPU (bit-exact vs CPU superaccumulator/MPFR)",
-            "value": n_total * args.steps / dt / 1e9,
+            "metric": f"{opname} fp64 Gelem/s at n=2^{args.log2n} (bit-exact vs CPU superaccumulator/MPFR)",
+            "value": head["value"],
             "unit": "Gelem/s",
-            "n_gpus": world,
+            "n_gpus": n_ranks_seen,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
+            "ms_per_step": head["ms_per_step"],
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": head["scaling"],
             "vs_baseline": None,
             "dtype": "f64",
             "data": f"synthetic ({args.kind} p0={args.p0:g} p1={args.p1:g}, counter-based generator, {nrot} distinct "
-                    f"vectors per GPU, seeds 1,3,5,...)",
-            "config": {"workload": f"Ex{args.op[2:].upper()} n=2^{args.log2n} fp64 {args.kind}"
-                                   f"(c={args.p0:g}) per GPU, fpe={args.fpe} early_exit={ee}, "
+                    f"vectors, seeds 1,3,5,...)",
+            "transport": transport,
+            "config": {"workload": f"{opname} {shape} fp64 {args.kind}(c={args.p0:g}), fpe={args.fpe} early_exit={ee}, "
                                    f"{world}xMI355X, inputs resident in HBM, steps rotate over {nrot} distinct vectors",
-                       "elements_per_gpu": n, "fpe": args.fpe, "early_exit": ee,
-                       "parallelism": (f"shard{world}, 576-byte digit set per step, {transport}"
-                                       if world > 1 else "single")},
-            "roofline": roof,
-            "result": result.exact,
+                       "n_total": head["n_total"], "fpe": args.fpe, "early_exit": ee, "parallelism": par},
         }
+        for k in ("roofline", "result", "result_bits", "result_bits_reference_rounding", "limbs_crc", "weak",
+                  "cpu_baseline", "bit_exact_vs_cpu", "bit_exact_detail"):
+            if k in head:
+                out[k] = head[k]
+        if "cpu_baseline" in head:
+            out["cpu_baseline_at_cgroup_quota_Gelems"] = head["cpu_baseline"]["value_at_cgroup_quota"]
         if secondary:
             out["exdot"] = secondary
         if blas23:
@@ -562,36 +782,30 @@ def main():
             gv["frac_hbm_peak"] = gv["GBs"] / HBM_PEAK_GBS
             gv["frac_hbm_peak_T"] = gv["bytes"] / (gv["ms_T"] * 1e-3) / 1e9 / HBM_PEAK_GBS
             gv["frac_hbm_peak_superacc_only"] = gv["bytes"] / (gv["ms_superacc_only"] * 1e-3) / 1e9 / HBM_PEAK_GBS
-            # algorithmic work of ExGEMM = 2*m*n*k flop; the roofline it is priced against is the fp64
-            # matrix peak.  mfma_util = issued MFMA work / the peak of the MFMA type the path actually uses: every
-            # element pair costs slices_a * slices_b MFMA multiply-adds (fp64 slices of 21 bits or int8 slices of 8).
+            # roofline.frac = what the matrix pipe that does the work is asked to do / its peak: every element pair
+            # costs products_per_pair multiply-adds of the MFMA type the path uses (int8 residues or digits: 5 Pop/s
+            # dense; fp64 slices: 78.6 TFLOP/s).  frac_2mnk (algorithmic 2mnk flop / the fp64 matrix
+            # peak) is kept beside it under its own name: it can exceed 1 because no fp64 unit does the work.
             t2 = gm["flop_2mnk"] / (gm["ms"] * 1e-3) / 1e12
             prods = gm.get("products_per_pair") or gm["slices"] ** 2
             issued = t2 * prods
-            peak_issue = I8_MFMA_PEAK_TOPS if str(gm.get("path", "")).startswith("mfma_i8") else F64_MFMA_PEAK_TF
+            i8 = str(gm.get("path", "")).startswith("mfma_i8")
+            peak_issue = (I8_MFMA_PEAK_TOPS if i8 else F64_MFMA_PEAK_TF) * world
             gm["TFLOPs_2mnk"] = t2
-            gm["roofline"] = {"bound": "mfma", "achieved": t2, "peak": F64_MFMA_PEAK_TF * world, "unit": "TFLOP/s",
-                              "frac": t2 / (F64_MFMA_PEAK_TF * world), "frac_2mnk": t2 / (F64_MFMA_PEAK_TF * world),
-                              "mfma_issued_Tops": issued, "mfma_issue_peak_Tops": peak_issue * world,
-                              "mfma_util": issued / (peak_issue * world),
+            gm["roofline"] = {"bound": "mfma", "achieved": issued, "peak": peak_issue,
+                              "unit": "Top/s (int8 multiply-add = 2 op)" if i8 else "TFLOP/s",
+                              "frac": issued / peak_issue,
+                              "frac_2mnk": t2 / (F64_MFMA_PEAK_TF * world),
+                              "frac_2mnk_note": "algorithmic 2mnk flop / time / fp64 matrix peak: NOT a utilisation",
                               "traffic": load_traffic(args.traffic_json, GEMM_KERNEL.get(gm.get("path"), "k_gemm")),
                               "kernel": GEMM_KERNEL.get(gm.get("path"), "k_gemm"),
-                              "note": "frac = frac_2mnk: algorithmic 2mnk flop / time / fp64 matrix peak (SURVEY 8(d)); it "
-                                      "can exceed 1 because the exact product runs on the int8 matrix cores (residues "
-                                      "modulo 8-bit moduli: products_per_pair int8 GEMMs); mfma_util = issued int8 "
-                                      "multiply-adds / the int8 peak"}
+                              "note": "whole call (scans, residues, contraction, reconstruction); the contraction "
+                                      "kernel alone: profiles/ kernel stats"}
             out["exgemv"] = gv
             out["exgemm"] = gm
             out["extrsv"] = blas23["extrsv"]
         if host_api:
             out["host_api"] = host_api
-        if host0 is not None:
-            base, parity = cpu_baseline(args.op, host0, args.fpe, ee, result)
-            out["cpu_baseline"] = base
-            out["cpu_baseline_at_cgroup_quota_Gelems"] = base["value_at_cgroup_quota"]
-            out["bit_exact_vs_cpu"] = bool(parity["limbs_equal"] and parity["double_equal_exact_rounding"] and
-                                           parity["double_equal_reference_rounding"])
-            out["bit_exact_detail"] = parity
         print(json.dumps(out), flush=True)
     if comm is not None:
         comm.destroy()

@@ -134,10 +134,10 @@ def load_library():
     L.exblas_exsum_allreduce_dev.argtypes = [vp, vp, i64, i64, i32, i32, vp, vp]
     L.exblas_exdot_allreduce_dev.argtypes = [vp, vp, i64, vp, i64, i64, i32, i32, vp, vp]
     L.exblas_allreduce_finish_dev.argtypes = [vp, vp, vp]
-    L.exblas_exgemv_sharded_dev.argtypes = [vp, C.c_char, i32, i32, dbl, vp, i32, vp, i32, i32, dbl, vp, i32, i32,
+    L.exblas_exgemv_sharded_dev.argtypes = [vp, C.c_char, i32, i32, dbl, vp, i32, vp, i32, i32, dbl, vp, i32, i32, i32,
                                             i32, vp]
     L.exblas_exgemm_sharded_dev.argtypes = [vp, C.c_char, C.c_char, i32, i32, i32, dbl, vp, i32, vp, i32, i32, dbl,
-                                            vp, i32, i32, i32, vp]
+                                            vp, i32, i32, i32, i32, vp]
     L.exblas_exsum_record.argtypes = [i32, vp, i32, i32, i32, i32, vp]
     L.exblas_exdot_record.argtypes = [i32, vp, i32, i32, vp, i32, i32, i32, i32, vp]
     _lib = L

@@ -358,11 +358,14 @@ int exblas_exdot_allreduce_dev(exblas_comm_t *cm, const double *d_a_local, int64
 }
 
 int exblas_exgemv_sharded_dev(exblas_comm_t *cm, char transa, int m, int n, double alpha, const double *d_a_local,
-                              int lda, double *d_x, int incx, int x_root, double beta, double *d_y, int incy, int fpe,
-                              int early_exit, void *stream)
+                              int lda, double *d_x, int incx, int x_root, double beta, double *d_y, int incy, int gather,
+                              int fpe, int early_exit, void *stream)
 {
     if (!cm || m < 0 || n < 0 || incx <= 0 || incy <= 0) return (int)hipErrorInvalidValue;
     if (m == 0 || n == 0) return 0;
+    // the reference's silent no-op (ExGEMV.cpp: early_exit with fpe > 8 matches no kernel): decided here, the same way on
+    // every rank, BEFORE any collective is posted
+    if (early_exit && fpe > 8) return 0;
     hipStream_t st = (hipStream_t)stream;
     const bool t = (transa == 'T' || transa == 't');
     const int inner = t ? m : n, outs = t ? n : m;  // length of x, length of y
@@ -383,7 +386,7 @@ int exblas_exgemv_sharded_dev(exblas_comm_t *cm, char transa, int m, int n, doub
                                    early_exit, stream);
         if (rc) return rc;
     }
-    if (!multi) return 0;
+    if (!multi || !gather) return 0;
     // rank r owns the elements [cut(r), cut(r+1)) of y, i.e. the bytes from cut(r)*incy on; the last piece ends with
     // the last element of y
     std::vector<int64_t> off(cm->nranks + 1);
@@ -400,10 +403,13 @@ int exblas_exgemv_sharded_dev(exblas_comm_t *cm, char transa, int m, int n, doub
 
 int exblas_exgemm_sharded_dev(exblas_comm_t *cm, char transa, char transb, int m, int n, int k, double alpha,
                               const double *d_a_local, int lda, double *d_b, int ldb, int b_root, double beta,
-                              double *d_c, int ldc, int fpe, int early_exit, void *stream)
+                              double *d_c, int ldc, int gather, int fpe, int early_exit, void *stream)
 {
     if (!cm || m < 0 || n < 0 || k < 0 || ldc < n) return (int)hipErrorInvalidValue;
     if (m == 0 || n == 0) return 0;
+    // the reference's silent no-op (ExGEMM.cpp:88-99) must be taken by every rank before any collective: a rank with
+    // rows would otherwise skip the chunk hooks that a rank without rows still posts
+    if (early_exit && fpe > 8) return 0;
     hipStream_t st = (hipStream_t)stream;
     const bool tb = (transb == 'T' || transb == 't');
     std::lock_guard<std::mutex> lk(cm->mu);
@@ -415,6 +421,12 @@ int exblas_exgemm_sharded_dev(exblas_comm_t *cm, char transa, char transb, int m
     const int R = cm->nranks;
     long long r0, r1;
     shard(m, cm->rank, R, &r0, &r1);
+    if (!gather) {
+        // C stays sharded: the rank's rows only, no collective at all (rows are independent units)
+        if (r1 <= r0) return 0;
+        return exgemm_chunked_dev(transa, transb, (int)(r1 - r0), n, k, alpha, d_a_local, lda, d_b, ldb, beta,
+                                  d_c + (size_t)r0 * ldc, ldc, fpe, early_exit, st, nullptr);
+    }
     // The operands are scanned and sliced ONCE; the local rows of C are then produced in NCH chunks (boundaries at
     // multiples of 256 local rows, the block height of the int8 kernels), and the all-gather of chunk c -- one piece per
     // rank -- runs on a side stream while chunk c+1 is computed.  Chunk boundaries are the same function of (m, R) on

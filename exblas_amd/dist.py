@@ -200,21 +200,22 @@ def allreduce_finish(comm, out=None):
 
 
 def exgemv_sharded(comm, trans, m, n, alpha, a_local, lda, x, beta, y, fpe=8, early_exit=True, x_root=0, incx=1,
-                   incy=1):
-    """y := alpha*op(A)*x + beta*y with the outputs sharded over the ranks; see ``exblas_exgemv_sharded_dev``."""
+                   incy=1, gather=True):
+    """y := alpha*op(A)*x + beta*y with the outputs sharded over the ranks; see ``exblas_exgemv_sharded_dev``.
+    gather=False leaves y sharded (only the rank's own part is written, no collective after the product)."""
     from . import load_library, _check, _require_gpu
     torch = _require_gpu()
     _check(load_library().exblas_exgemv_sharded_dev(comm.handle, trans.encode(), m, n, alpha,
                                                     C.c_void_p(a_local.data_ptr()), lda, C.c_void_p(x.data_ptr()),
-                                                    incx, x_root, beta, C.c_void_p(y.data_ptr()), incy, fpe,
-                                                    int(early_exit), _args(torch)), "exgemv_sharded_dev")
+                                                    incx, x_root, beta, C.c_void_p(y.data_ptr()), incy, int(gather),
+                                                    fpe, int(early_exit), _args(torch)), "exgemv_sharded_dev")
     return y
 
 
 def exgemm_sharded(comm, m, n, k, alpha, a_local, b, beta, c, fpe=8, early_exit=True, b_root=0, transa="N",
-                   transb="N", lda=None, ldb=None, ldc=None):
+                   transb="N", lda=None, ldb=None, ldc=None, gather=True):
     """C := alpha*op(A)*op(B) + beta*C (row-major) with the rows sharded over the ranks; see
-    ``exblas_exgemm_sharded_dev``."""
+    ``exblas_exgemm_sharded_dev``.  gather=False leaves C sharded (with b_root < 0: no collective at all)."""
     from . import load_library, _check, _require_gpu
     torch = _require_gpu()
     lda = lda if lda is not None else (k if transa in "Nn" else m)
@@ -222,8 +223,8 @@ def exgemm_sharded(comm, m, n, k, alpha, a_local, b, beta, c, fpe=8, early_exit=
     ldc = ldc if ldc is not None else n
     _check(load_library().exblas_exgemm_sharded_dev(comm.handle, transa.encode(), transb.encode(), m, n, k, alpha,
                                                     C.c_void_p(a_local.data_ptr()), lda, C.c_void_p(b.data_ptr()),
-                                                    ldb, b_root, beta, C.c_void_p(c.data_ptr()), ldc, fpe,
-                                                    int(early_exit), _args(torch)), "exgemm_sharded_dev")
+                                                    ldb, b_root, beta, C.c_void_p(c.data_ptr()), ldc, int(gather),
+                                                    fpe, int(early_exit), _args(torch)), "exgemm_sharded_dev")
     return c
 
 

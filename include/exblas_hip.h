@@ -233,19 +233,24 @@ int exblas_allreduce_finish_dev(exblas_comm_t *comm, void *stream, int64_t *d_ou
  * d_a_local is that row block (column-major, leading dimension lda >= last - first).  transa 'T': rank r owns the
  * OUTPUTS [first, last) of n, i.e. columns first..last-1 of A; d_a_local points at column `first`.  d_x is the full
  * vector on every rank; x_root >= 0 broadcasts it from that rank first, x_root < 0 says it is already replicated.
- * d_y is the full vector on every rank: on entry a rank's own part holds its input (beta != 0), on return every rank
- * holds all of y (in-place all-gather). */
+ * d_y is the full vector on every rank: on entry a rank's own part holds its input (beta != 0); gather != 0: on return
+ * every rank holds all of y (in-place all-gather); gather == 0: only the rank's own part is written and NO collective
+ * is issued after the product (y stays sharded: what a caller that keeps iterating on row blocks wants).
+ * early_exit with fpe > 8 is the reference's silent no-op: nothing is computed or communicated, on any rank. */
 int exblas_exgemv_sharded_dev(exblas_comm_t *comm, char transa, int m, int n, double alpha, const double *d_a_local,
-                              int lda, double *d_x, int incx, int x_root, double beta, double *d_y, int incy, int fpe,
-                              int early_exit, void *stream);
+                              int lda, double *d_x, int incx, int x_root, double beta, double *d_y, int incy, int gather,
+                              int fpe, int early_exit, void *stream);
 /* Row-sharded ExGEMM (row-major): rank r owns rows [first, last) = exblas_shard_range(m, r, size) of op(A) and C;
  * d_a_local points at the rank's first row of op(A) (for transa 'T': column `first` of the stored k x m matrix).
  * d_b: all of op(B)'s storage on every rank, broadcast from b_root first when b_root >= 0.  d_c: the full m x ldc
- * matrix on every rank; a rank's own rows hold its input (beta != 0); on return every rank holds all of C.  With the
- * RCCL transport the all-gather of a finished row chunk overlaps the computation of the next one. */
+ * matrix on every rank; a rank's own rows hold its input (beta != 0).  gather != 0: on return every rank holds all of C
+ * (with the RCCL transport the all-gather of a finished row chunk overlaps the computation of the next one);
+ * gather == 0: only the rank's own rows are written, no collective follows the product -- with b_root < 0 the call
+ * then issues no collective at all (rows of C are independent units; the reference has no distributed GEMM to imitate,
+ * and an m x n all-gather costs more than the product itself from 4 GPUs up). */
 int exblas_exgemm_sharded_dev(exblas_comm_t *comm, char transa, char transb, int m, int n, int k, double alpha,
                               const double *d_a_local, int lda, double *d_b, int ldb, int b_root, double beta,
-                              double *d_c, int ldc, int fpe, int early_exit, void *stream);
+                              double *d_c, int ldc, int gather, int fpe, int early_exit, void *stream);
 
 /* ---- (1) host-pointer layer (reference semantics; copies H2D per call like gpu:ExSUM.cpp:126) -- */
 /* exsum / exdot of host vectors spread one call over several GPUs of the node (each streams its contiguous part in

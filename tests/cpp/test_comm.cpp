@@ -64,14 +64,14 @@ int main()
         // ExGEMM, rows in 4 chunks with the RCCL transport
         CK(hipMemset(C, 0, (size_t)m * nn * 8)); CK(hipMemset(C2, 0, (size_t)m * nn * 8));
         CK(exblas_exgemm_dev('N', 'N', m, nn, k, 1.0, A, k, B, nn, 0.0, C, nn, 8, 1, nullptr));
-        CK(exblas_exgemm_sharded_dev(comm, 'N', 'N', m, nn, k, 1.0, A, k, B, nn, 0, 0.0, C2, nn, 8, 1, nullptr));
+        CK(exblas_exgemm_sharded_dev(comm, 'N', 'N', m, nn, k, 1.0, A, k, B, nn, 0, 0.0, C2, nn, /*gather*/ 1, 8, 1, nullptr));
         std::vector<double> c1((size_t)m * nn), c2((size_t)m * nn);
         CK(hipMemcpy(c1.data(), C, c1.size() * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(c2.data(), C2, c2.size() * 8, hipMemcpyDeviceToHost));
         if (memcmp(c1.data(), c2.data(), c1.size() * 8)) { pass = false; printf("exgemm differs (%d)\n", transport); }
         // ExGEMV 'T' on the same storage read column-major (k x m matrix with lda = k: outputs = its m columns)
         CK(hipMemset(yv, 0, (size_t)m * 8)); CK(hipMemset(yv2, 0, (size_t)m * 8));
         CK(exblas_exgemv_dev('T', k, m, 1.0, A, k, B, 1, 0.0, yv, 1, 8, 1, nullptr));
-        CK(exblas_exgemv_sharded_dev(comm, 'T', k, m, 1.0, A, k, B, 1, 0, 0.0, yv2, 1, 8, 1, nullptr));
+        CK(exblas_exgemv_sharded_dev(comm, 'T', k, m, 1.0, A, k, B, 1, 0, 0.0, yv2, 1, /*gather*/ 1, 8, 1, nullptr));
         std::vector<double> y1(m), y2(m);
         CK(hipMemcpy(y1.data(), yv, m * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(y2.data(), yv2, m * 8, hipMemcpyDeviceToHost));
         if (memcmp(y1.data(), y2.data(), m * 8)) { pass = false; printf("exgemv differs (%d)\n", transport); }

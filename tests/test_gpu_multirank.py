@@ -86,6 +86,46 @@ def _run_all(ex, torch, comm, rank, world):
             ex.exgemm_sharded(comm, M, N, K, 1.0, A[r0 * K:], Bm, 1.0, Cm, fpe, ee)
             assert (Bm == B).all()
         out[f"gemm{fpe}"] = Cm.cpu().numpy().view(np.int64).tolist()
+    # gather = 0: y / C stay sharded -- only the rank's own block is written and no collective follows the product
+    # (B / x already replicated: b_root = x_root = -1, so the call posts no collective at all).  The untouched part keeps
+    # its sentinel; the own block equals the single-rank result.
+    sentinel = -12345.0
+    yS = torch.full((M,), sentinel, dtype=torch.float64, device="cuda")
+    yS[r0:r1] = yv[:M][r0:r1]
+    Cs = torch.full((M * N,), sentinel, dtype=torch.float64, device="cuda")
+    Cs[r0 * N:r1 * N] = C0[r0 * N:r1 * N]
+    if comm is None:
+        yS[:] = yv[:M]
+        Cs[:] = C0
+        ex.exgemv_dev("N", M, N, 1.5, a_cm, M, xv[:N].clone(), 1.0, yS, 8, True)
+        ex.exgemm_dev("N", "N", M, N, K, 1.0, A, K, B, N, 1.0, Cs, N, 8, True)
+        out["sharded_nogather"] = (yS.cpu().numpy().view(np.int64).tolist(), Cs.cpu().numpy().view(np.int64).tolist())
+    else:
+        a_loc = a_cm.view(N, M)[:, r0:r1].contiguous()
+        ex.exgemv_sharded(comm, "N", M, N, 1.5, a_loc, max(r1 - r0, 1), xv[:N].clone(), 1.0, yS, 8, True, x_root=-1,
+                          gather=False)
+        ex.exgemm_sharded(comm, M, N, K, 1.0, A[r0 * K:], B, 1.0, Cs, 8, True, b_root=-1, gather=False)
+        yh, ch = yS.cpu().numpy(), Cs.cpu().numpy()
+        mask_y = np.ones(M, bool); mask_y[r0:r1] = False
+        mask_c = np.ones(M * N, bool); mask_c[r0 * N:r1 * N] = False
+        assert (yh[mask_y] == sentinel).all() and (ch[mask_c] == sentinel).all()
+        out["sharded_nogather"] = (r0, r1, yh[r0:r1].view(np.int64).tolist(), ch[r0 * N:r1 * N].view(np.int64).tolist())
+    # the reference's silent no-op (early_exit with fpe > 8) in a communicator where some ranks own no rows (m = 2 over
+    # 3 ranks): every rank must return without posting a collective (a mismatch would hang the transport)
+    if comm is not None:
+        m2 = 2
+        q0, q1 = ex.row_block(m2, rank, world)
+        C2 = torch.full((m2 * N,), 7.0, dtype=torch.float64, device="cuda")
+        ex.exgemm_sharded(comm, m2, N, K, 1.0, A[q0 * K:], B.clone(), 1.0, C2, 9, True)
+        y2 = torch.full((m2,), 7.0, dtype=torch.float64, device="cuda")
+        ex.exgemv_sharded(comm, "N", m2, N, 1.0, a_cm, max(q1 - q0, 1), xv[:N].clone(), 1.0, y2, 9, True)
+        assert (C2 == 7.0).all() and (y2 == 7.0).all()
+        # ... and the same shapes with a variant that does compute: ranks without rows still take part in every chunk
+        C3 = torch.zeros(m2 * N, dtype=torch.float64, device="cuda")
+        ex.exgemm_sharded(comm, m2, N, K, 1.0, A[q0 * K:], B.clone(), 0.0, C3, 8, True)
+        want = torch.zeros(m2 * N, dtype=torch.float64, device="cuda")
+        ex.exgemm_dev("N", "N", m2, N, K, 1.0, A, K, B, N, 0.0, want, N, 8, True)
+        assert torch.equal(C3.view(torch.int64), want.view(torch.int64))
     torch.cuda.synchronize()
     return out
 
@@ -126,10 +166,15 @@ def test_shared_gpu_ranks_bit_identical(world):
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
+    y_one, c_one = one["sharded_nogather"]
     for rank, out in res:
         assert out.keys() == one.keys()
         for key in one:
-            assert out[key] == one[key], (world, rank, key)
+            if key == "sharded_nogather":
+                r0, r1, yb, cb = out[key]
+                assert yb == y_one[r0:r1] and cb == c_one[r0 * N:r1 * N], (world, rank, key)
+            else:
+                assert out[key] == one[key], (world, rank, key)
 
 
 def test_rccl_transport_one_rank():
@@ -143,7 +188,10 @@ def test_rccl_transport_one_rank():
     one = _run_all(ex, torch, None, 0, 1)
     got = _run_all(ex, torch, comm, 0, 1)
     for key in one:
-        assert got[key] == one[key], key
+        if key == "sharded_nogather":
+            assert list(got[key][2:]) == list(one[key]), key
+        else:
+            assert got[key] == one[key], key
     # row chunks: 2200 local rows are produced in 4 chunks (cuts at multiples of 64 rows), each shipped by its own group
     # of broadcasts on the side stream while the next chunk is computed; operands scanned and sliced once
     m, n, k = 2200, 96, 130
