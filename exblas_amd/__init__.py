@@ -37,7 +37,7 @@ C_ABI_SYMBOLS = [
     "exblas_exsum_allreduce_dev", "exblas_exdot_allreduce_dev", "exblas_allreduce_finish_dev",
     "exblas_exgemv_sharded_dev", "exblas_exgemm_sharded_dev", "exblas_last_gemm_info", "exblas_set_gemm_max_slices",
     "exblas_set_gemm_max_moduli", "exblas_crt_selftest",
-    "exblas_set_host_devices",
+    "exblas_set_host_devices", "exblas_workspace_bytes",
 ]
 
 # host-transport callback types of include/exblas_hip.h
@@ -113,6 +113,7 @@ def load_library():
     L.exblas_exgemv.argtypes = [C.c_char, i32, i32, dbl, vp, i32, i32, vp, i32, i32, dbl, vp, i32, i32, i32, i32]
     L.exblas_exgemm.argtypes = [C.c_char, C.c_char, i32, i32, i32, dbl, vp, i32, vp, i32, dbl, vp, i32, i32, i32]
     L.exblas_reserve_workspace.argtypes = [C.c_size_t]
+    L.exblas_workspace_bytes.restype = C.c_size_t
     L.exblas_set_host_devices.argtypes = [i32, C.POINTER(C.c_int)]
     L.exblas_last_gemm_info.argtypes = [C.POINTER(C.c_int)]
     L.exblas_set_gemm_max_slices.argtypes = [i32]

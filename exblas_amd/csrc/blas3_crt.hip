@@ -350,13 +350,14 @@ template <bool CONTIG>
 __global__ void __launch_bounds__(256) k_crt_residues(const double *__restrict__ src, long long ld, int nvec, int len,
                                                       double scale, const int *__restrict__ E,
                                                       const int *__restrict__ info, int which,
-                                                      signed char *__restrict__ planes, size_t plane_stride)
+                                                      signed char *__restrict__ planes, size_t plane_stride, int vt0)
 {
     if (info[INFO_PATH] != PATH_CRT) return;
     const int L = info[INFO_CRT_L], need = info[which ? INFO_CRT_NB : INFO_CRT_NA];
+    // vt: tile index inside `planes` (a row chunk of A' starts at vector tile vt0; B: vt0 = 0)
     const int kc = blockIdx.x, vt = blockIdx.y, KC = gridDim.x;
     const int r = CONTIG ? (threadIdx.x >> 2) : (threadIdx.x & 63), seg = CONTIG ? (threadIdx.x & 3) : (threadIdx.x >> 6);
-    const int v = vt * I8_T + r, l0 = kc * I8_T + seg * 16;
+    const int v = (vt0 + vt) * I8_T + r, l0 = kc * I8_T + seg * 16;
     const int u = (v < nvec ? E[v] : 0) - need;
     signed char *tile = planes + ((size_t)vt * KC + kc) * I8_TILE + tile_off(r, seg * 16);
     const int nw = (need + 31) >> 5;  // 32-bit words of |X| in use (wave-uniform): the loops carry no branches
@@ -376,7 +377,9 @@ __global__ void __launch_bounds__(256) k_crt_residues(const double *__restrict__
 // and issues 2 x 16 MFMAs; the fragments of the next k-step and one staging instruction are issued between the MFMAs
 // of the current k-step, one barrier per chunk.
 // Result: R[modulus][row / 4][col] = the four residues (rows 4g .. 4g+3, unsigned bytes) of C mod p_t.
-__global__ void __launch_bounds__(256, 1) k_gemm_crt(int n, int row_end, int ty0, int ty_cnt, int gy, int gx, int KC,
+// PA holds the residue planes of the row chunk that starts at tile row ty0 (ty_cnt tile rows), R the residues of the same
+// rows of C (m4 = groups of four rows in the chunk).
+__global__ void __launch_bounds__(256, 1) k_gemm_crt(int n, int row_end, int ty0, int ty_cnt, int gx, int KC,
                                                      int kc0, int kc1, const signed char *__restrict__ PA,
                                                      const signed char *__restrict__ PB,
                                                      size_t plane_a, size_t plane_b, const int *__restrict__ info,
@@ -397,7 +400,7 @@ __global__ void __launch_bounds__(256, 1) k_gemm_crt(int n, int row_end, int ty0
     const signed char *ga[4], *gb[4];  // wave-uniform tile streams; the lane offset is added at the load
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int ta = min(ty0 + by * 4 + i, gy - 1), tb = min(bx * 4 + i, gx - 1);  // ragged edge: a valid tile again
+        const int ta = min(by * 4 + i, ty_cnt - 1), tb = min(bx * 4 + i, gx - 1);  // ragged edge: a valid tile again
         ga[i] = PA + (size_t)mod * plane_a + (size_t)ta * KC * I8_TILE;
         gb[i] = PB + (size_t)mod * plane_b + (size_t)tb * KC * I8_TILE;
     }
@@ -507,7 +510,7 @@ __global__ void __launch_bounds__(256, 1) k_gemm_crt(int n, int row_end, int ty0
                 }
                 const int gi = row_base + pu * 32 + 8 * a4 + 4 * half, gj = col_base + qu * 32;
                 if (gi < row_end && gj < n) {
-                    unsigned *dst = R + ((size_t)mod * m4 + (gi >> 2)) * n + gj;
+                    unsigned *dst = R + ((size_t)mod * m4 + ((gi - ty0 * I8_T) >> 2)) * n + gj;
                     if (kc0 > 0) {  // a later k block (k > 8192): add to the residues of the earlier ones
                         const unsigned old = *dst;
                         unsigned sum = 0;
@@ -641,6 +644,7 @@ __global__ void __launch_bounds__(256) k_crt_finish(int row0, int row1, int n, c
                                                     double *__restrict__ c, long long ldc, int round_mode,
                                                     const unsigned *__restrict__ R, int m4, int all)
 {
+    // R: the residues of the row chunk that starts at row0 (m4 groups of four rows)
     if (info[INFO_PATH] != PATH_CRT) return;
     const int L = info[INFO_CRT_L], na = info[INFO_CRT_NA], nb = info[INFO_CRT_NB];
     // words that hold the sum of up to 13 terms below M_L each (4 bits of headroom)
@@ -649,9 +653,9 @@ __global__ void __launch_bounds__(256) k_crt_finish(int row0, int row1, int n, c
     const long long loc = (long long)blockIdx.x * 256 + threadIdx.x;
     const int groups = (row1 - row0 + 3) >> 2;
     if (loc >= (long long)groups * n) return;
-    const int g = (row0 >> 2) + (int)(loc / n), gj = (int)(loc % n);
+    const int gl = (int)(loc / n), g = (row0 >> 2) + gl, gj = (int)(loc % n);
     const size_t stride = (size_t)m4 * n;
-    const unsigned *rp = R + (size_t)g * n + gj;
+    const unsigned *rp = R + (size_t)gl * n + gj;
 #define CRT_FIN(NW) crt_finish_body<NW>(L, na, nb, g, gj, row1, rp, stride, EA, EB, beta, c, ldc, round_mode)
     if constexpr (WIDE) {
         if (nw <= 8 && !all) CRT_FIN(8);
@@ -668,6 +672,14 @@ __global__ void __launch_bounds__(256) k_crt_finish(int row0, int row1, int n, c
 // ---------------------------------------------------------------------------------------------
 // host side: a pure sequence of launches (same two-step shape as the digit path: whole operands, then rows of C)
 // ---------------------------------------------------------------------------------------------
+// Workspace: info | EA EB LA LB | residue planes of B (whole, lcap moduli) | residue planes of ONE row chunk of A' |
+// residues of the same rows of C.  The rows of C are produced chunk by chunk (crt_chunk_rows: 2048 rows once m exceeds
+// 3072), each chunk = residues of its rows of A', the contractions, the reconstruction -- so only B's planes scale with
+// the whole problem: 8192^3 reserves 39 x (64 + 16 + 16) MiB = 3.7 GiB (was 39 x 192 MiB = 7.3 GiB with whole-matrix
+// planes of A' and R), 16384^3 12.2 GiB (was 29 GiB), and the chunk's planes (0.3 GiB for 18 moduli) stay in the
+// Infinity Cache's reach between the kernels that write and read them.
+static int crt_chunk_rows(int m) { return m > 3072 ? 2048 : ((m + 255) / 256) * 256; }
+
 hipError_t exgemm_crt_prepare(Ctx &c, char transa, char transb, int m, int n, int k, double alpha, const double *a, int lda,
                               const double *b, int ldb, double beta, double *cmat, int ldc, int round_mode,
                               hipStream_t st, I8Plan *plan)
@@ -675,31 +687,42 @@ hipError_t exgemm_crt_prepare(Ctx &c, char transa, char transb, int m, int n, in
     plan->ok = false;
     if (k <= 0 || m <= 0 || n <= 0) return hipSuccess;
     const int ta = (transa == 'T' || transa == 't'), tb = (transb == 'T' || transb == 't');
-    const int gy = (m + I8_T - 1) / I8_T, gx = (n + I8_T - 1) / I8_T, KC = (k + I8_T - 1) / I8_T;
+    const int gx = (n + I8_T - 1) / I8_T, KC = (k + I8_T - 1) / I8_T;
     int lcap = c.gemm_max_moduli > 0 ? c.gemm_max_moduli : CRT_LMAX;
     if (lcap > CRT_LMAX) lcap = CRT_LMAX;
     int clog2k = 0;
     while ((1ll << clog2k) < (long long)k) ++clog2k;
-    const int m4 = (m + 3) / 4;
-    // workspace: info | EA EB LA LB | residue planes of A | of B | R
-    size_t off = 0;
+    const int chunk = crt_chunk_rows(m), ctiles = chunk / I8_T, cm4 = chunk / 4;
+    const size_t plane_a = (size_t)ctiles * KC * I8_TILE, plane_b = (size_t)gx * KC * I8_TILE;
+    size_t off = 0, o_info = 0, o_e = 0, o_pa = 0, o_pb = 0, o_r = 0;
     auto take = [&](size_t bytes) {
         const size_t o = off;
         off += (bytes + 255) & ~(size_t)255;
         return o;
     };
-    const size_t plane_a = (size_t)gy * KC * I8_TILE, plane_b = (size_t)gx * KC * I8_TILE;
-    const size_t o_info = take(sizeof(int) * INFO_WORDS);
-    const size_t o_e = take(sizeof(int) * 2 * ((size_t)m + n));
-    const size_t o_pa = take(plane_a * lcap);
-    const size_t o_pb = take(plane_b * lcap);
-    const size_t o_r = take((size_t)lcap * m4 * n * sizeof(unsigned));
+    auto layout = [&](int l) {
+        off = 0;
+        o_info = take(sizeof(int) * INFO_WORDS);
+        o_e = take(sizeof(int) * 2 * ((size_t)m + n));
+        o_pb = take(plane_b * l);
+        o_pa = take(plane_a * l);
+        o_r = take((size_t)l * cm4 * n * sizeof(unsigned));
+    };
+    // Out of memory: retry with fewer moduli (24 cover 53-bit mantissas with 30 binades of spread inside a row at
+    // k = 8192, 18 what fpuniform(10) needs); data that needs more than were reserved takes the scalar kernel, decided
+    // on the device as always.  c.gemm_ws_moduli records what was reserved (exblas_last_gemm_info out[4]).
     hipError_t e = hipSuccess;
-    char *base = (char *)workspace(c, off, st, &e);
-    if (!base) {
-        if (e == hipErrorStreamCaptureUnsupported) return e;  // the caller must reserve before capturing
-        return hipSuccess;                                    // out of memory: scalar kernel
+    char *base = nullptr;
+    const int tries[4] = {lcap, 24, 18, 12};
+    for (int t = 0; t < 4 && !base; ++t) {
+        if (t > 0 && tries[t] >= lcap) continue;
+        if (t > 0) lcap = tries[t];
+        layout(lcap);
+        base = (char *)workspace(c, off, st, &e);
+        if (!base && e == hipErrorStreamCaptureUnsupported) return e;  // the caller must reserve before capturing
     }
+    c.gemm_ws_moduli = base ? lcap : 0;
+    if (!base) return hipSuccess;  // out of memory even for 12 moduli: the caller falls back (digit path, scalar kernel)
     int *info = (int *)(base + o_info);
     int *EA = (int *)(base + o_e), *EB = EA + m, *LA = EB + n, *LB = LA + m;
     signed char *PA = (signed char *)(base + o_pa), *PB = (signed char *)(base + o_pb);
@@ -720,24 +743,20 @@ hipError_t exgemm_crt_prepare(Ctx &c, char transa, char transb, int m, int n, in
     hipLaunchKernelGGL(k_scan_finish, dim3((n + 255) / 256), dim3(256), 0, st, n, EB, LB, info, INFO_NEED_B);
     hipLaunchKernelGGL(k_crt_decide, dim3(1), dim3(64), 0, st, info, clog2k, lcap);
 
-    if (!ta)
-        hipLaunchKernelGGL((k_crt_residues<true>), dim3(KC, gy), dim3(256), 0, st, a, (long long)lda, m, k, alpha, EA, info,
-                           0, PA, plane_a);
-    else
-        hipLaunchKernelGGL((k_crt_residues<false>), dim3(KC, gy), dim3(256), 0, st, a, (long long)lda, m, k, alpha, EA,
-                           info, 0, PA, plane_a);
+    // B's residues once for all row chunks; A's per chunk (exgemm_crt_rows)
     if (!tb)
         hipLaunchKernelGGL((k_crt_residues<false>), dim3(KC, gx), dim3(256), 0, st, b, (long long)ldb, n, k, 1.0, EB, info,
-                           1, PB, plane_b);
+                           1, PB, plane_b, 0);
     else
         hipLaunchKernelGGL((k_crt_residues<true>), dim3(KC, gx), dim3(256), 0, st, b, (long long)ldb, n, k, 1.0, EB, info,
-                           1, PB, plane_b);
+                           1, PB, plane_b, 0);
     plan->ok = true;
     plan->crt = true;
     plan->m = m; plan->n = n; plan->KC = KC;
     plan->info = info; plan->EA = EA; plan->EB = EB; plan->PA = PA; plan->PB = PB;
     plan->R = (unsigned *)(base + o_r);
-    plan->plane_a = plane_a; plan->plane_b = plane_b; plan->lcap = lcap; plan->m4 = m4;
+    plan->plane_a = plane_a; plan->plane_b = plane_b; plan->lcap = lcap; plan->m4 = cm4;
+    plan->chunk_rows = chunk; plan->a = a; plan->lda = lda; plan->alpha = alpha; plan->ta = ta; plan->k = k;
     // tuning variants 21..25: 1, 2, 3, 6 moduli per launch / all in one; default: by the number of tiles (exgemm_crt_rows)
     plan->mods_per_launch = c.variant == 21 ? 1 : (c.variant == 22 ? 2 : (c.variant == 23 ? 3 : (c.variant == 24 ? 6 : (c.variant == 25 ? lcap : 0))));
     plan->num_cu = c.num_cu;
@@ -746,41 +765,48 @@ hipError_t exgemm_crt_prepare(Ctx &c, char transa, char transb, int m, int n, in
     return hipGetLastError();
 }
 
-// rows [row0, row1) of C, row0 a multiple of 64
+// rows [row0, row1) of C, row0 a multiple of 64; internally in chunks of plan.chunk_rows rows
 hipError_t exgemm_crt_rows(const I8Plan &p, int row0, int row1, hipStream_t st)
 {
-    if (row1 <= row0) return hipSuccess;
-    const int gy = (p.m + I8_T - 1) / I8_T, gx = (p.n + I8_T - 1) / I8_T;
-    const int ty0 = row0 / I8_T, ty_cnt = (row1 - row0 + I8_T - 1) / I8_T;
-    const int by_cnt = (ty_cnt + 3) / 4, bx_cnt = (gx + 3) / 4;
-    // A few moduli per launch (three at 8192^2).  The workgroups of an XCD share their A / B tile streams through its L2 only while they
-    // run in step; they start in step at the beginning of a launch and drift apart afterwards (12 rounds of 256 workgroups
-    // per launch here, 72 with all 18 moduli in one launch): 15 GB through the fabric per 8192^3 call against 30.5 GB,
-    // 11.3 ms against 11.5 (1 per launch: 14.5 GB, 11.4 ms).  Launches for moduli the data does not need exit at once.
-    // In general: about 12 rounds of one workgroup per CU per launch.
-    int per = p.mods_per_launch;
-    if (per <= 0) {
-        const long long tiles = (long long)by_cnt * bx_cnt;
-        per = (int)max(1ll, min((long long)p.lcap, (12ll * p.num_cu) / max(1ll, tiles)));
-    }
-    for (int kc0 = 0; kc0 < p.KC; kc0 += CRT_KPASS)
-        for (int mod0 = 0; mod0 < p.lcap; mod0 += per) {
-            const int nm = min(per, p.lcap - mod0);
-            hipLaunchKernelGGL(k_gemm_crt, dim3((unsigned)(nm * by_cnt * bx_cnt)), dim3(256), 0, st, p.n, row1, ty0, ty_cnt,
-                               gy, gx, p.KC, kc0, min(p.KC, kc0 + CRT_KPASS), p.PA, p.PB, p.plane_a, p.plane_b, p.info, p.R,
-                               p.m4, mod0);
+    const int gx = (p.n + I8_T - 1) / I8_T, bx_cnt = (gx + 3) / 4;
+    for (int c0 = row0; c0 < row1; c0 += p.chunk_rows) {
+        const int c1 = min(row1, c0 + p.chunk_rows);
+        const int ty0 = c0 / I8_T, ty_cnt = (c1 - c0 + I8_T - 1) / I8_T, by_cnt = (ty_cnt + 3) / 4;
+        // residues of this chunk's rows of A' = fl(alpha * A)
+        if (!p.ta)
+            hipLaunchKernelGGL((k_crt_residues<true>), dim3(p.KC, ty_cnt), dim3(256), 0, st, p.a, (long long)p.lda, p.m, p.k,
+                               p.alpha, p.EA, p.info, 0, p.PA, p.plane_a, ty0);
+        else
+            hipLaunchKernelGGL((k_crt_residues<false>), dim3(p.KC, ty_cnt), dim3(256), 0, st, p.a, (long long)p.lda, p.m,
+                               p.k, p.alpha, p.EA, p.info, 0, p.PA, p.plane_a, ty0);
+        // A few moduli per launch.  The workgroups of an XCD share their A / B tile streams through its L2 only while
+        // they run in step; they start in step at the beginning of a launch and drift apart afterwards: about 12 rounds
+        // of one workgroup per CU per launch (8192^3, whole-matrix launches: 15 GB through the fabric per call with 12
+        // rounds, 30.5 GB with 72).  Launches for moduli the data does not need exit at once.
+        int per = p.mods_per_launch;
+        if (per <= 0) {
+            const long long tiles = (long long)by_cnt * bx_cnt;
+            per = (int)max(1ll, min((long long)p.lcap, (12ll * p.num_cu) / max(1ll, tiles)));
         }
-    const long long groups = (row1 - row0 + 3) / 4;
+        for (int kc0 = 0; kc0 < p.KC; kc0 += CRT_KPASS)
+            for (int mod0 = 0; mod0 < p.lcap; mod0 += per) {
+                const int nm = min(per, p.lcap - mod0);
+                hipLaunchKernelGGL(k_gemm_crt, dim3((unsigned)(nm * by_cnt * bx_cnt)), dim3(256), 0, st, p.n, c1, ty0, ty_cnt,
+                                   gx, p.KC, kc0, min(p.KC, kc0 + CRT_KPASS), p.PA, p.PB, p.plane_a, p.plane_b, p.info,
+                                   p.R, p.m4, mod0);
+            }
+        const long long groups = (c1 - c0 + 3) / 4;
 #define CRT_FIN(WIDE, ALL)                                                                                               \
-    hipLaunchKernelGGL((k_crt_finish<WIDE>), dim3((unsigned)((groups * p.n + 255) / 256)), dim3(256), 0, st, row0, row1,  \
+    hipLaunchKernelGGL((k_crt_finish<WIDE>), dim3((unsigned)((groups * p.n + 255) / 256)), dim3(256), 0, st, c0, c1,      \
                        p.n, p.info, p.EA, p.EB, p.beta, p.c, (long long)p.ldc, p.round_mode, p.R, p.m4, ALL)
-    if (groups * p.n < (1 << 18)) {
-        CRT_FIN(true, 1);  // small products are launch-bound: one kernel (10 words) for every width
-    } else {
-        CRT_FIN(false, 0);
-        CRT_FIN(true, 0);
-    }
+        if (groups * p.n < (1 << 18)) {
+            CRT_FIN(true, 1);  // small products are launch-bound: one kernel (10 words) for every width
+        } else {
+            CRT_FIN(false, 0);
+            CRT_FIN(true, 0);
+        }
 #undef CRT_FIN
+    }
     return hipGetLastError();
 }
 

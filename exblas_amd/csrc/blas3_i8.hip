@@ -492,8 +492,12 @@ hipError_t exgemm_i8_prepare(Ctx &c, char transa, char transb, int m, int n, int
 {
     plan->ok = false;
     if (k <= 0 || m <= 0 || n <= 0) return hipSuccess;
-    if (c.gemm_path == 4 || (c.gemm_path == 0 && m >= CRT_MIN_EDGE && n >= CRT_MIN_EDGE))
-        return exgemm_crt_prepare(c, transa, transb, m, n, k, alpha, a, lda, b, ldb, beta, cmat, ldc, round_mode, st, plan);
+    if (c.gemm_path == 4 || (c.gemm_path == 0 && m >= CRT_MIN_EDGE && n >= CRT_MIN_EDGE)) {
+        hipError_t e = exgemm_crt_prepare(c, transa, transb, m, n, k, alpha, a, lda, b, ldb, beta, cmat, ldc, round_mode, st,
+                                          plan);
+        // not enqueued although nothing failed = no memory even for 12 moduli: try the digit-slice workspace below
+        if (e != hipSuccess || plan->ok || c.gemm_path == 4) return e;
+    }
     const int ta = (transa == 'T' || transa == 't'), tb = (transb == 'T' || transb == 't');
     const int gy = (m + I8_T - 1) / I8_T, gx = (n + I8_T - 1) / I8_T, KC = (k + I8_T - 1) / I8_T;
     int scap = c.gemm_max_slices > 0 ? c.gemm_max_slices : I8_SCAP;

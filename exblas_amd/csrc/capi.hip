@@ -153,19 +153,25 @@ void *workspace(Ctx &c, size_t bytes, hipStream_t st, hipError_t *err)
             *err = hipErrorStreamCaptureUnsupported;
             return nullptr;
         }
-        // the old block is parked, not freed: a graph captured earlier may still replay into it
-        if (c.ws) c.retired.push_back(c.ws);
+        // Allocate FIRST: only a successful growth may change the context.  On failure ws / ws_bytes / retired stay as
+        // they were (the live block must never also sit in `retired`: a later exblas_release_retired_workspaces()
+        // would free memory the next call launches into) and the failed hipMalloc's error is cleared, so that the
+        // fallback path's hipGetLastError() does not report it.
         size_t cap = bytes + (c.ws_bytes >> 1);  // geometric growth bounds what the parked blocks can add up to
         void *p = nullptr;
         hipError_t e = hipMalloc(&p, cap);
         if (e != hipSuccess) {
+            (void)hipGetLastError();
             cap = bytes;
             e = hipMalloc(&p, cap);
         }
         if (e != hipSuccess) {
+            (void)hipGetLastError();
             *err = e;
             return nullptr;
         }
+        // the old block is parked, not freed: a graph captured earlier may still replay into it
+        if (c.ws) c.retired.push_back(c.ws);
         c.ws = p;
         c.ws_bytes = cap;
     }
@@ -381,6 +387,7 @@ int exblas_last_gemm_info(int *out)
             out[1] = h[11];          // INFO_CRT_NA: bits of the fixed-point entries of A'
             out[2] = h[12];          // INFO_CRT_NB
             out[3] = h[10];          // INFO_CRT_L: moduli = int8 GEMMs
+            out[4] = c.gemm_ws_moduli;  // moduli the workspace was reserved for (39 unless memory ran short)
         }
     } else if (c.last_gemm_slices > 0) {
         out[0] = 1;
@@ -574,6 +581,13 @@ int exblas_reserve_workspace(size_t bytes)
     hipError_t e = hipSuccess;
     workspace(c, bytes, nullptr, &e);
     return (int)e;
+}
+
+size_t exblas_workspace_bytes(void)
+{
+    Ctx &c = ctx(-1);
+    std::lock_guard<std::mutex> lk(c.mu);
+    return c.ws_bytes;
 }
 
 int exblas_release_retired_workspaces(void)

@@ -31,6 +31,7 @@ struct Ctx {
                              // 4: residues always; 1: scalar kernel only; 3: fp64 slices on MFMA-F64 (host-decided)
     int gemm_max_slices = 0; // 0 = default (16): digits per operand the int8 path reserves workspace for
     int gemm_max_moduli = 0; // 0 = default (39): moduli the residue path reserves workspace for
+    int gemm_ws_moduli = 0;  // moduli the last residue-path call actually reserved for (fewer after an out-of-memory retry)
     long long *gacc = nullptr;   // ACTIVE accumulator set: [ngroups][NL] int64, zero between calls
     unsigned *gflags = nullptr;  // non-finite input flags of the active set, zero between calls
     // two sets, so that the finalize of step i (side stream) can overlap the streaming kernel of step i+1
@@ -106,6 +107,10 @@ struct I8Plan {
     unsigned *R = nullptr;
     size_t plane_a = 0, plane_b = 0;
     int lcap = 0, m4 = 0, mods_per_launch = 0, num_cu = 256;
+    // residue path: A' is reduced row chunk by row chunk (PA / R hold one chunk)
+    int chunk_rows = 0, lda = 0, ta = 0, k = 0;
+    const double *a = nullptr;
+    double alpha = 1.0;
     double beta = 0.0;
     double *c = nullptr;
     int ldc = 0, round_mode = 0;

@@ -84,21 +84,28 @@ int exblas_set_tuning(int blocks_per_cu, int ngroups, int variant);
 void exblas_set_gemm_path(int mode);
 /* digits per operand the digit-slice path may use (workspace: that many bytes per matrix entry); 0 = default 16 */
 void exblas_set_gemm_max_slices(int s);
-/* moduli the residue path may use (workspace: that many bytes per entry of A, B and 4-row group of C);
- * 0 = default 39 = every input the path accepts (126 bits per operand) */
+/* moduli the residue path may use (workspace: that many bytes per entry of B and of a 2048-row chunk of A and C);
+ * 0 = default 39 = every input the path accepts (126 bits per operand).  When the reservation fails the call retries with
+ * 24, 18 and 12 moduli (data that needs more then takes the scalar kernel), then with the digit-slice workspace. */
 void exblas_set_gemm_max_moduli(int l);
 /* Which implementation the last exgemm on this device used: out[0] = 0 scalar kernel / 1 fp64 slices / 2 int8 digit
  * slices / 4 int8 residues.  Slices: out[1], out[2] = slices of A, B (out[1]*out[2] matrix multiply-adds per element
  * pair).  Residues: out[1], out[2] = bits of the fixed-point entries of A, B; out[3] = moduli (= matrix multiply-adds
- * per element pair).  Synchronises the device when the decision was taken there.  exblas_last_gemm_slices() =
+ * per element pair); out[4] = moduli the workspace was reserved for (39, fewer after an out-of-memory retry).  Synchronises the device when the decision was taken there.  exblas_last_gemm_slices() =
  * max(out[1], out[2]) for the slice paths, out[3] for residues, 0 for the scalar kernel. */
 int exblas_last_gemm_info(int *out8);
 /* CPU-only self-test of the residue path's constant tables and reconstruction formulas: `cases` random integers per
  * modulus count through a host mirror of the device arithmetic; returns the number of failures (0 = pass). */
 int exblas_crt_selftest(int cases, unsigned seed);
 int exblas_last_gemm_slices(void);
-/* Makes the *_dev layer's workspace at least `bytes` large (see "Workspace and hipGraphs" above). */
+/* Makes the *_dev layer's workspace at least `bytes` large (see "Workspace and hipGraphs" above).  A request that cannot
+ * be met returns the hipError_t and leaves the current workspace (and the parked blocks) exactly as they were. */
 int exblas_reserve_workspace(size_t bytes);
+/* Bytes the *_dev layer's workspace holds right now on the current device (the parked blocks not included).  Footprint of
+ * the residue path of exgemm: 39 bytes per entry of B, of a 2048-row chunk of A and of a 2048-row chunk of C --
+ * 8192^3: 3.7 GiB, 16384^3: 12.2 GiB; the digit-slice path: 16 bytes per entry of A and B (+ 40 per entry of C when more
+ * than one pass can be needed). */
+size_t exblas_workspace_bytes(void);
 /* Frees the workspace blocks that later, larger calls replaced.  Synchronises the device; only call it when no graph
  * captured before the growth will be replayed again. */
 int exblas_release_retired_workspaces(void);

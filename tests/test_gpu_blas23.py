@@ -103,11 +103,11 @@ def test_exgemm_trans_alpha_beta(ex, oracle):
 
 def gemm_info(lib):
     """(path, slices of A, slices of B) of the last exgemm: path 0 scalar kernel, 1 fp64 slices, 2 int8 digit slices;
-    4 int8 residues: (4, bits of A, bits of B, moduli)"""
+    4 int8 residues: (4, bits of A, bits of B, moduli, moduli the workspace was reserved for)"""
     import ctypes as C
     v = (C.c_int * 8)()
     assert lib.exblas_last_gemm_info(v) == 0
-    return (v[0], v[1], v[2], v[3]) if v[0] == 4 else (v[0], v[1], v[2])
+    return (v[0], v[1], v[2], v[3], v[4]) if v[0] == 4 else (v[0], v[1], v[2])
 
 
 # cumulative bits of the residue path's moduli 256, 255, 253, 251, 247, 241, ... (floor(log2(product of the first L)))
@@ -208,6 +208,73 @@ def test_exgemm_residue_vs_digits_midsize(ex, oracle, ta, tb, m, n, k):
     else:
         want = oracle.exgemm(ta, tb, rows, n, k, -0.75, ha[:rows * lda], lda, hb, ldb, 2.0, hc0[:rows * n].copy(), n, 0)
     assert (_bits(outs[4].cpu().numpy()[:rows * n]) == _bits(want)).all()
+
+
+@pytest.mark.parametrize("ta", ["N", "T"])
+def test_exgemm_residue_row_chunks(ex, oracle, ta):
+    """m > 3072: the residue path reduces A' and reconstructs C in row chunks of 2048 rows that share one chunk-sized
+    workspace (planes of A', residues of C); the last chunk is ragged (not a multiple of 256, 64 or 4 rows).  Every
+    entry equals the digit-slice path, rows from every chunk equal the oracle, beta = 1 reads the right rows of C."""
+    import torch
+    lib = ex.load_library()
+    m, n, k = 2 * 2048 + 203, 260, 150
+    lda = (m if ta == "T" else k) + 1
+    A = ex.gen_dev("fpuniform_signed", (k if ta == "T" else m) * lda, 171, 12, 6)
+    B = ex.gen_dev("fpuniform_signed", k * n, 172, 10, 5)
+    C0 = ex.gen_dev("fpuniform_signed", m * n, 173, 10, 5)
+    outs = {}
+    try:
+        for path in (4, 2):
+            lib.exblas_set_gemm_path(path)
+            C = C0.clone()
+            ex.exgemm_dev(ta, "N", m, n, k, 1.0, A, lda, B, n, 1.0, C, n, 8, True)
+            torch.cuda.synchronize()
+            assert gemm_info(lib)[0] == path
+            outs[path] = C
+    finally:
+        lib.exblas_set_gemm_path(0)
+    assert torch.equal(outs[4].view(torch.int64), outs[2].view(torch.int64))
+    ha, hb, hc0, got = A.cpu().numpy(), B.cpu().numpy(), C0.cpu().numpy(), outs[4].cpu().numpy()
+    for r0 in (0, 2040, 4090, m - 9):            # rows around every chunk boundary and the ragged tail
+        rows = min(9, m - r0)
+        if ta == "T":
+            a_blk = np.ascontiguousarray(ha.reshape(k, lda)[:, r0:r0 + rows]).reshape(-1)
+            want = oracle.exgemm("T", "N", rows, n, k, 1.0, a_blk, rows, hb, n, 1.0, hc0[r0 * n:(r0 + rows) * n].copy(), n, 0)
+        else:
+            want = oracle.exgemm("N", "N", rows, n, k, 1.0, ha[r0 * lda:(r0 + rows) * lda], lda, hb, n, 1.0,
+                                 hc0[r0 * n:(r0 + rows) * n].copy(), n, 0)
+        assert (_bits(got[r0 * n:(r0 + rows) * n]) == _bits(want)).all(), (ta, r0)
+
+
+def test_workspace_failed_growth_leaves_context_intact(ex, oracle):
+    """A reservation that cannot be met must not touch the live workspace: afterwards it is neither parked (a later
+    exblas_release_retired_workspaces() would free memory the next call launches into) nor resized, the failed
+    hipMalloc leaves no error behind, and calls that fit the old block keep working."""
+    import torch
+    lib = ex.load_library()
+    m, n = 700, 300
+    a, x, y0 = oracle.gen("fpuniform_signed", m * n, 51, 10, 5), oracle.gen("fpuniform", n, 52, 10, 0), np.zeros(m)
+    want = oracle.exgemv("N", m, n, 1.0, a, m, x, 0.0, y0, 0)
+    A, X = torch.from_numpy(a).cuda(), torch.from_numpy(x).cuda()
+    Y = torch.zeros(m, dtype=torch.float64, device="cuda")
+    ex.exgemv_dev("N", m, n, 1.0, A, m, X, 0.0, Y, 0, False)       # makes sure a workspace exists
+    torch.cuda.synchronize()
+    before = lib.exblas_workspace_bytes()
+    assert before > 0
+    rc = lib.exblas_reserve_workspace(1 << 50)                        # a petabyte: must fail
+    assert rc != 0
+    assert lib.exblas_workspace_bytes() == before
+    assert lib.exblas_release_retired_workspaces() == 0               # must not free the live block
+    for fpe, ee in ((0, False), (8, True)):
+        Y.zero_()
+        ex.exgemv_dev("N", m, n, 1.0, A, m, X, 0.0, Y, fpe, ee)
+        torch.cuda.synchronize()
+        assert (_bits(Y.cpu().numpy()) == _bits(want)).all()
+    assert lib.exblas_release_workspace() == 0                        # and no double free
+    Y.zero_()
+    ex.exgemv_dev("N", m, n, 1.0, A, m, X, 0.0, Y, 8, True)
+    torch.cuda.synchronize()
+    assert (_bits(Y.cpu().numpy()) == _bits(want)).all()
 
 
 def test_exgemm_residue_path_long_k_and_capacity(ex, oracle):
@@ -444,25 +511,35 @@ def test_full_size_configs_stripes(ex, oracle):
     N = 8192
     Am = ex.gen_dev("fpuniform", N * N, 14, 10.0, 0.0)
     Bm = ex.gen_dev("fpuniform", N * N, 15, 10.0, 0.0)
-    C = torch.zeros(N * N, dtype=torch.float64, device="cuda")
-    ex.exgemm_dev("N", "N", N, N, N, 1.0, Am, N, Bm, N, 0.0, C, N, 8, True)
+    # alpha = beta = 1 as in the reference test (tests/test.exgemm.gpu.cpp:183-184): C += Round(A B)
+    C0 = ex.gen_dev("fpuniform_signed", N * N, 18, 10.0, 5.0)
+    C = C0.clone()
+    assert lib.exblas_release_workspace() == 0             # measure what THIS call reserves
+    ex.exgemm_dev("N", "N", N, N, N, 1.0, Am, N, Bm, N, 1.0, C, N, 8, True)
     assert lib.exblas_last_gemm_slices() >= 2              # the fast (MFMA) path ran
-    r0 = 5120
+    info = gemm_info(lib)
+    assert info[0] == 4 and info[4] == 39, info            # residues, reserved for every input the path accepts
+    # footprint: 39 bytes per entry of B, of a 2048-row chunk of A and of C (was 39 x 3 x 64 MiB = 7.3 GiB)
+    assert lib.exblas_workspace_bytes() <= 4 * 10**9, lib.exblas_workspace_bytes()
+    r0 = 5120                                              # a stripe inside the third of the four row chunks
     stripe = C.view(N, N)[r0:r0 + 256].clone()
-    Cs = torch.zeros(256 * N, dtype=torch.float64, device="cuda")
+    Cs = C0[r0 * N:(r0 + 256) * N].clone()
     lib.exblas_set_gemm_path(1)                            # scalar kernel only
     try:
-        ex.exgemm_dev("N", "N", 256, N, N, 1.0, Am[r0 * N:], N, Bm, N, 0.0, Cs, N, 8, True)
+        ex.exgemm_dev("N", "N", 256, N, N, 1.0, Am[r0 * N:], N, Bm, N, 1.0, Cs, N, 8, True)
         assert lib.exblas_last_gemm_slices() == 0
     finally:
         lib.exblas_set_gemm_path(0)
     assert torch.equal(stripe.view(-1).view(torch.int64), Cs.view(torch.int64)), "gemm stripe: fast path != scalar kernel"
     j0 = 4000
-    Ab = Am.view(N, N)[r0:r0 + 256].contiguous().cpu().numpy().reshape(-1)
-    Bb = Bm.view(N, N)[:, j0:j0 + 48].contiguous().cpu().numpy().reshape(-1)
-    wantc = oracle.exgemm("N", "N", 256, 48, N, 1.0, Ab, N, Bb, 48, 0.0, np.zeros(256 * 48), 48, 0)
-    got = stripe[:, j0:j0 + 48].contiguous().cpu().numpy().reshape(-1)
-    assert (_bits(got) == _bits(wantc)).all(), "gemm block vs oracle"
+    hc0 = C0.view(N, N)
+    for rb in (r0, 2040, N - 256):                         # blocks across a chunk boundary and at the end
+        blk = C.view(N, N)[rb:rb + 256, j0:j0 + 48].contiguous().cpu().numpy().reshape(-1)
+        Ab = Am.view(N, N)[rb:rb + 256].contiguous().cpu().numpy().reshape(-1)
+        Bb = Bm.view(N, N)[:, j0:j0 + 48].contiguous().cpu().numpy().reshape(-1)
+        c0b = hc0[rb:rb + 256, j0:j0 + 48].contiguous().cpu().numpy().reshape(-1)
+        wantc = oracle.exgemm("N", "N", 256, 48, N, 1.0, Ab, N, Bb, 48, 1.0, c0b, 48, 0)
+        assert (_bits(blk) == _bits(wantc)).all(), ("gemm block vs oracle", rb)
 
 
 def same_bits(x, y):
