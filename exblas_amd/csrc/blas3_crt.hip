@@ -37,14 +37,15 @@ constexpr int CRT_KPASS = 128;    // k chunks (of 64) per launch: 8192 * 2^14 = 
 
 struct CrtTables {
     int p[CRT_LMAX];
-    float invp[CRT_LMAX];            // a shade below 1/p: the truncated quotient is never too large
+    float invp[CRT_LMAX];            // 1/p rounded to float
     unsigned c8[CRT_LMAX][4];        // 256^t mod p for t = 0..15, byte t%4 of word t/4
     int bits[CRT_LMAX + 1];          // floor(log2(M_L)), M_L = p_0 ... p_{L-1}
-    double gp[CRT_G][3], gip[CRT_G][3];             // the moduli of group b and their reciprocals
-    double gi01[CRT_G], gi02[CRT_G], gi12[CRT_G];   // p0^-1 mod p1, p0^-1 mod p2, p1^-1 mod p2
     double P[CRT_G][3], invP[CRT_G][3];             // super-modulus of group b when it holds w + 1 moduli
     // with L moduli in use (the last group then holds L - 3 (G - 1) of its three):
     double wc[CRT_LMAX + 1][CRT_G];                 // (M_L / P_b)^-1 mod P_b
+    // gc[L][b][j] = wc[L][b] * e_j mod P_b, e_j the CRT basis of modulus j inside group b (1 mod p_j, 0 mod the others;
+    // 0 for a modulus the last group does not use):  y_b = (sum_j r_j gc[L][b][j]) mod P_b  in one reduction
+    double gc[CRT_LMAX + 1][CRT_G][3];
     unsigned MP[CRT_LMAX + 1][CRT_G][CRT_W32];      // M_L / P_b
     unsigned M[CRT_LMAX + 1][CRT_W32];              // M_L
 };
@@ -119,7 +120,7 @@ const CrtTables &crt_tables_host()
         }
         for (int i = 0; i < CRT_LMAX; ++i) {
             const int p = t.p[i];
-            t.invp[i] = (float)((1.0 / p) * (1.0 - 1.0 / (1 << 22)));
+            t.invp[i] = (float)(1.0 / p);
             long long pw = 1;
             for (int d = 0; d < 16; ++d) {
                 t.c8[i][d >> 2] |= (unsigned)(pw % p) << (8 * (d & 3));
@@ -128,14 +129,6 @@ const CrtTables &crt_tables_host()
         }
         for (int b = 0; b < CRT_G; ++b) {
             const long long p0 = t.p[3 * b], p1 = t.p[3 * b + 1], p2 = t.p[3 * b + 2];
-            const long long pp[3] = {p0, p1, p2};
-            for (int j = 0; j < 3; ++j) {
-                t.gp[b][j] = (double)pp[j];
-                t.gip[b][j] = 1.0 / (double)pp[j];
-            }
-            t.gi01[b] = (double)inv_mod(p0, p1);
-            t.gi02[b] = (double)inv_mod(p0, p2);
-            t.gi12[b] = (double)inv_mod(p1, p2);
             const long long Pw[3] = {p0, p0 * p1, p0 * p1 * p2};
             for (int w = 0; w < 3; ++w) {
                 t.P[b][w] = (double)Pw[w];
@@ -155,7 +148,15 @@ const CrtTables &crt_tables_host()
                 Big q = mm;
                 q.div_small(Pb);  // exact
                 for (int i = 0; i < CRT_W32; ++i) t.MP[l][b][i] = q.w[i];
-                t.wc[l][b] = (double)inv_mod((long long)q.mod_small(Pb), (long long)Pb);
+                const long long wcl = inv_mod((long long)q.mod_small(Pb), (long long)Pb);
+                t.wc[l][b] = (double)wcl;
+                for (int j = 0; j < 3; ++j) {
+                    t.gc[l][b][j] = 0.0;
+                    if (j >= w) continue;
+                    const long long pj = t.p[3 * b + j], rest = (long long)Pb / pj;
+                    const long long ej = (rest * inv_mod(rest % pj, pj)) % (long long)Pb;   // < 2^24
+                    t.gc[l][b][j] = (double)((wcl * ej) % (long long)Pb);                    // < 2^48 before the reduction
+                }
             }
         }
     });
@@ -173,18 +174,11 @@ __host__ __device__ __forceinline__ double crt_dmod(double z, double P, double i
     return r;
 }
 
-// z mod P up to one multiple of P either way: a value in [-P, 2P) congruent to z.  Enough for the intermediate steps
-// (everything stays an exact integer far below 2^53; only the last reduction of a group must be canonical).
-__host__ __device__ __forceinline__ double crt_dmod_lazy(double z, double P, double invP)
-{
-    return fma(-floor(z * invP), P, z);
-}
-
 // Thread = (group of 4 rows, column): the L words R[t][g][j] hold the residues of its 4 entries, loaded two groups of
-// moduli ahead of their use.  Per group of three moduli: Garner inside the group gives the residue x_b modulo the
-// 24-bit super-modulus P_b; then the classical formula  value = sum_b y_b (M / P_b) - kappa M,  y_b = x_b (M / P_b)^-1
-// mod P_b:  the big products in 32-bit words, kappa = round(sum_b y_b / P_b) in fp64 -- exact because |value| / M < 1/4
-// (k_crt_decide) while the fraction sum is good to 1e-14.  The table entries of a group are wave-uniform scalars, read
+// moduli ahead of their use.  Moduli in groups of three with the 24-bit super-modulus P_b; the classical formula on two
+// levels:  value = sum_b y_b (M / P_b) - kappa M,  y_b = x_b (M / P_b)^-1 mod P_b = (sum_j r_j gc_j) mod P_b (x_b the
+// residue modulo P_b, never formed):  the big products in 32-bit words, kappa = round(sum_b y_b / P_b) in fp64 -- exact
+// because |value| / M < 1/4 (k_crt_decide) while the fraction sum is good to 1e-14.  The table entries of a group are wave-uniform scalars, read
 // once for the four entries.
 // Host mirror of k_crt_finish's arithmetic over the same tables (CPU-only check of the table generator and of the
 // reconstruction formulas, tests/test_abi.py): random integers |S| < M_L / 4 for every L -> residues -> groups ->
@@ -224,16 +218,8 @@ static int crt_selftest_host(int cases, unsigned seed)
                     if (neg && m) m = p - m;
                     r[j] = (double)m;
                 }
-                double x = r[0];
-                if (w >= 2) {
-                    const double v1 = crt_dmod_lazy((r[1] - r[0]) * t.gi01[b], t.gp[b][1], t.gip[b][1]);
-                    x = fma(t.gp[b][0], v1, r[0]);
-                    if (w >= 3) {
-                        const double v2 = crt_dmod_lazy(((r[2] - r[0]) * t.gi02[b] - v1) * t.gi12[b], t.gp[b][2], t.gip[b][2]);
-                        x = fma(t.P[b][1], v2, x);
-                    }
-                }
-                const double y = crt_dmod(x * t.wc[L][b], t.P[b][w - 1], t.invP[b][w - 1]);
+                const double x = fma(r[2], t.gc[L][b][2], fma(r[1], t.gc[L][b][1], r[0] * t.gc[L][b][0]));  // < 2^34: exact
+                const double y = crt_dmod(x, t.P[b][w - 1], t.invP[b][w - 1]);
                 phi = fma(y, t.invP[b][w - 1], phi);
                 const uint32_t yb = (uint32_t)y;
                 uint64_t carry = 0;
@@ -309,7 +295,7 @@ __device__ __forceinline__ void crt_residues_body(const double *__restrict__ src
                                                   size_t plane_stride)
 {
     unsigned w[NW][16];
-    unsigned negmask = 0;
+    unsigned sgn[16];   // the element's sign, as the float sign bit
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int l = l0 + e;
@@ -320,12 +306,11 @@ __device__ __forceinline__ void crt_residues_body(const double *__restrict__ src
         if constexpr (NW > 1) w[1][e] = (unsigned)(X.lo >> 32);
         if constexpr (NW > 2) w[2][e] = (unsigned)X.hi;
         if constexpr (NW > 3) w[3][e] = (unsigned)((unsigned long long)X.hi >> 32);
-        negmask |= (x < 0.0 ? 1u : 0u) << e;
+        sgn[e] = x < 0.0 ? 0x80000000u : 0u;
     }
 #pragma unroll 1
     for (int t = 0; t < L; ++t) {
-        const unsigned p = (unsigned)g_crt.p[t], hi = (p - 1u) >> 1;
-        const float invp = g_crt.invp[t];
+        const float pf = (float)g_crt.p[t], invp = g_crt.invp[t];
         unsigned c[NW];
 #pragma unroll
         for (int j = 0; j < NW; ++j) c[j] = g_crt.c8[t][j];
@@ -335,12 +320,14 @@ __device__ __forceinline__ void crt_residues_body(const double *__restrict__ src
             unsigned s = 0;
 #pragma unroll
             for (int j = 0; j < NW; ++j) s = __builtin_amdgcn_udot4(w[j][e], c[j], s, false);
-            const unsigned q = (unsigned)((float)s * invp);  // s < 2^20: exact float; q = floor(s/p) or one less
-            unsigned rr = s - __umul24(q, p);                // q < 2^15, p <= 256: the full-rate 24-bit multiply
-            rr = min(rr, rr - p);                            // rr >= p  ->  rr - p (unsigned wrap otherwise)
-            int sv = (int)rr - (rr > hi ? (int)p : 0);       // symmetric residue in [-(p-1)/2 .. (p-1)/2], p = 256: [-128, 127]
-            sv = ((negmask >> e) & 1u) ? -sv : sv;           // p = 256: -(-128) wraps to -128 = 128 mod 256
-            pk.b[e] = (signed char)sv;
+            // symmetric residue in float: s < 2^20 and q p < 2^21 are exact floats, so r = s - rint(s / p) p is exact;
+            // |s invp - s / p| < 2^-11 puts r within p / 2 + 1/8 of zero: |r| <= (p - 1) / 2 for the odd moduli, <= 128
+            // for p = 256 (+128 wraps to -128 = 128 mod 256 in the int8 plane).  The sign of the element is applied to
+            // s (rint is odd).  Four instructions where the integer form (truncated quotient, 24-bit multiply, two
+            // fix-ups, centring, sign select) took eleven.
+            const float sf = __uint_as_float(__float_as_uint((float)s) ^ sgn[e]);
+            const float r = fmaf(-rintf(sf * invp), pf, sf);
+            pk.b[e] = (signed char)(int)r;
         }
         *(v4i_t *)(tile + (size_t)t * plane_stride) = pk.v;
     }
@@ -549,31 +536,21 @@ __device__ __forceinline__ void crt_finish_body(int L, int na, int nb, int g, in
 #pragma unroll
         for (int i = 0; i < NW; ++i) acc[o][i] = 0u;
     }
-    // one group of moduli for the four entries; W = 3: a full group (no branches), W = 0: w moduli, known at run time
-    auto group = [&](auto wc_, int b, int w, const unsigned (&cur)[3]) {
-        constexpr int W = decltype(wc_)::value;
-        const double p0 = g_crt.gp[b][0], p1 = g_crt.gp[b][1], p2 = g_crt.gp[b][2];
-        const double ip1 = g_crt.gip[b][1], ip2 = g_crt.gip[b][2];
-        const double i01 = g_crt.gi01[b], i02 = g_crt.gi02[b], i12 = g_crt.gi12[b], p01 = g_crt.P[b][1];
-        const double Pb = g_crt.P[b][w - 1], iPb = g_crt.invP[b][w - 1], wcb = g_crt.wc[L][b];
+    // one group of moduli for the four entries: classical CRT inside the group folded with the group's weight --
+    // y_b = (r_0 c_0 + r_1 c_1 + r_2 c_2) mod P_b with c_j = gc[L][b][j] < 2^24 (zero for a modulus the last group does not
+    // use), the sum an exact integer below 2^34; three multiply-adds and ONE reduction per entry and group (the Garner
+    // form it replaces: two lazy reductions + the canonical one, ~25 fp64 instructions)
+    auto group = [&](int b, int w, const unsigned (&cur)[3]) {
+        const double c0 = g_crt.gc[L][b][0], c1 = g_crt.gc[L][b][1], c2 = g_crt.gc[L][b][2];
+        const double Pb = g_crt.P[b][w - 1], iPb = g_crt.invP[b][w - 1];
         unsigned mp[NW];
 #pragma unroll
         for (int i = 0; i < NW; ++i) mp[i] = g_crt.MP[L][b][i];
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
-            const double r0 = (double)((cur[0] >> (8 * o)) & 255u);
-            double x = r0;
-            if (W == 3 || w >= 2) {
-                const double r1 = (double)((cur[1] >> (8 * o)) & 255u);
-                const double v1 = crt_dmod_lazy((r1 - r0) * i01, p1, ip1);
-                x = fma(p0, v1, r0);
-                if (W == 3 || w >= 3) {
-                    const double r2 = (double)((cur[2] >> (8 * o)) & 255u);
-                    const double v2 = crt_dmod_lazy(((r2 - r0) * i02 - v1) * i12, p2, ip2);
-                    x = fma(p01, v2, x);
-                }
-            }
-            const double y = crt_dmod(x * wcb, Pb, iPb);
+            const double r0 = (double)((cur[0] >> (8 * o)) & 255u), r1 = (double)((cur[1] >> (8 * o)) & 255u),
+                         r2 = (double)((cur[2] >> (8 * o)) & 255u);
+            const double y = crt_dmod(fma(r2, c2, fma(r1, c1, r0 * c0)), Pb, iPb);
             phi[o] = fma(y, iPb, phi[o]);
             const unsigned yb = (unsigned)y;
             unsigned long long carry = 0;
@@ -591,14 +568,14 @@ __device__ __forceinline__ void crt_finish_body(int L, int na, int nb, int g, in
 #pragma unroll 1
     for (int b = 0; b < G - 1; ++b) {
         fetch(b + 2, nx2);
-        group(std::integral_constant<int, 3>{}, b, 3, cur);
+        group(b, 3, cur);
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             cur[j] = nx1[j];
             nx1[j] = nx2[j];
         }
     }
-    group(std::integral_constant<int, 0>{}, G - 1, wlast, cur);
+    group(G - 1, wlast, cur);
     const int ebj = EB[gj] - nb;
 #pragma unroll 1
     for (int o = 0; o < 4; ++o) {
