@@ -17,11 +17,16 @@
 
 #include <algorithm>
 
+// tools/ only: a device buffer of 2 x (workgroups x 4) uint64 that k_gemvN_fpe_sx fills with per-wave start / end clocks
+// (100 MHz wall clock); nullptr (the default) = off.  Not part of the C ABI (not declared in include/).
+extern "C" void *exblas_debug_timeline = nullptr;
+
 namespace exb {
 
 constexpr int GV_BLOCK = 256;
 constexpr int GV_WAVES = GV_BLOCK / 64;
 constexpr int GV_KC = 1024;  // columns of x staged in LDS at a time (8 KiB)
+constexpr int GV_TICKET_STRIDE = 4096 + 256;  // bytes between two ticket counters of k_gemvN_fpe_sx
 
 // ---------------------------------------------------------------------------------------------
 // 'N', expansion path: two rows per lane
@@ -106,12 +111,18 @@ __global__ void __launch_bounds__(256) k_scale_x(int n, double alpha, const doub
 // vector is read with scalar loads (one s_load_dwordx16 per 8 columns) and enters the TwoProd as an SGPR operand -- no
 // LDS staging of x, no workgroup barriers, no fragment registers for it.  The early-exit vote is one fp64 compare
 // per residue (the lane masks are OR-ed by the scalar unit).  Otherwise as k_gemvN_fpe (two rows per lane).
-template <int N, bool EE, int U = 8>
-__global__ void __launch_bounds__(GV_BLOCK) k_gemvN_fpe_sx(int m, int n, const double *__restrict__ a, long long lda,
+template <int N, bool EE, int U = 8, bool TL = false>
+__global__ void __launch_bounds__(GV_BLOCK, 4) k_gemvN_fpe_sx(int m, int n, const double *__restrict__ a, long long lda,
                                                            const double *__restrict__ xa, int kper,
-                                                           double *__restrict__ part, long long *__restrict__ ws, int il)
+                                                           double *__restrict__ part, long long *__restrict__ ws, int il,
+                                                           int *__restrict__ tickets,
+                                                           unsigned long long *__restrict__ timeline)
 {
     const int tid = threadIdx.x;
+    // TL: tools only (exblas_debug_timeline; a separate instantiation, the production kernels carry no trace of it):
+    // start / end clock of every wave
+    if (TL && (tid & 63) == 0)
+        timeline[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * GV_WAVES + (tid >> 6)) * 2] = wall_clock64();
     const long long r0 = ((long long)blockIdx.x * GV_BLOCK + tid) * 2;
     const int ks = blockIdx.y, KS = gridDim.y;
     const int k0 = ks * kper, k1 = min(n, k0 + kper);
@@ -124,31 +135,63 @@ __global__ void __launch_bounds__(GV_BLOCK) k_gemvN_fpe_sx(int m, int n, const d
         // il = 1: the k splits take the groups of U columns round-robin (split ks: groups ks, ks + KS, ...) instead of
         // one contiguous range each (+1-2 %).  il = 2: in addition a group is every SECOND column of a block of 2U (even
         // ones, then odd ones), so the loads a wave has in flight are 2 lda apart -- the 256 KiB column stride of
-        // lda = 32768 is the one that costs 9 % (tools/gemv_lda.py), 512 KiB does not.
+        // lda = 32768 is the one that costs 9 % (tools/gemv_lda.py), 512 KiB does not.  il = 3 (production): the groups
+        // of il = 2, handed out dynamically.
         static_assert(U == 8, "column groups are blocks of 16");
-        const int cs = il == 2 ? 2 : 1;                          // column step inside a group
-        const int nfull = il == 2 ? (n / (2 * U)) * 2 * U : (n / U) * U;  // columns covered by whole groups
-        auto group_k = [&](int gg) { return il == 2 ? (gg >> 1) * 2 * U + (gg & 1) : gg * U; };
-        if (il) {
-            for (int g = ks; g < nfull / U; g += KS) {
-                const int k = group_k(g);
-                const double *col = a + r0 + lda * k;
-                double ax[U], ay[U], xs[U];
+        const int cs = il >= 2 ? 2 : 1;                          // column step inside a group
+        const int nfull = il >= 2 ? (n / (2 * U)) * 2 * U : (n / U) * U;  // columns covered by whole groups
+        auto group_k = [&](int gg) { return il >= 2 ? (gg >> 1) * 2 * U + (gg & 1) : gg * U; };
+        // one counter per 128 rows, GV_TICKET_STRIDE bytes apart: device-scope atomics execute at the memory side, and 256
+        // counters in one 1 KiB line made every draw of the whole chip queue at ONE channel (1.74 ms against 1.46 static)
+        int *ctr = tickets + (size_t)(blockIdx.x * GV_WAVES + (tid >> 6)) * (GV_TICKET_STRIDE / sizeof(int));
+        auto draw = [&]() {
+            int t = 0;
+            if ((tid & 63) == 0) t = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return t;   // lane 0's value; read with readfirstlane where it is used
+        };
+        int drawn = 0;
+        auto do_group = [&](int g, bool draw_after_loads) {
+            const int k = group_k(g);
+            const double *col = a + r0 + lda * k;
+            double ax[U], ay[U], xs[U];
 #pragma unroll
-                for (int j = 0; j < U; ++j) {
-                    const d2_t r = ld2<true>((const d2_t *)(col + lda * (cs * j)));
-                    ax[j] = r.x;
-                    ay[j] = r.y;
-                    xs[j] = xa[k + cs * j];  // uniform address: scalar load
-                }
-                double p[U], e[U];
-#pragma unroll
-                for (int j = 0; j < U; ++j) p[j] = two_prod(ax[j], xs[j], e[j]);
-                fpe_absorb_prod<N, EE, U, GlobalSink, 1>(f0, p, e, s0);
-#pragma unroll
-                for (int j = 0; j < U; ++j) p[j] = two_prod(ay[j], xs[j], e[j]);
-                fpe_absorb_prod<N, EE, U, GlobalSink, 1>(f1, p, e, s1);
+            for (int j = 0; j < U; ++j) {
+                const d2_t r = ld2<true>((const d2_t *)(col + lda * (cs * j)));
+                ax[j] = r.x;
+                ay[j] = r.y;
+                xs[j] = xa[k + cs * j];  // uniform address: scalar load
             }
+            if (draw_after_loads) drawn = draw();  // behind the loads in the (in-order) return queue: it cannot hold them up
+            double p[U], e[U];
+#pragma unroll
+            for (int j = 0; j < U; ++j) p[j] = two_prod(ax[j], xs[j], e[j]);
+            fpe_absorb_prod<N, EE, U, GlobalSink, 1>(f0, p, e, s0);
+#pragma unroll
+            for (int j = 0; j < U; ++j) p[j] = two_prod(ay[j], xs[j], e[j]);
+            fpe_absorb_prod<N, EE, U, GlobalSink, 1>(f1, p, e, s1);
+        };
+        if (il == 3) {
+            // DYNAMIC: the KS waves that own the same 128 rows (one per k split) draw column groups from a shared counter.
+            // The four workgroups resident on a CU do not run at the same pace -- the instruction arbiter favours the
+            // oldest: at 32768^2 with static ranges they finished at 1010 / 1081 / 1238 / 1412 us (tools/gemv_timeline.py),
+            // the CU draining from four waves per SIMD to one over the last 30 % of the kernel.  Every row segment has
+            // waves of all four ages, so with a shared counter they all run dry together.  The sum is exact, so which
+            // wave adds which columns cannot change a bit.  A ticket is TB groups (32 KiB of matrix per wave); tickets
+            // are drawn TWO ahead and the atomic is issued behind the loads of a group, so its (long, device-scope)
+            // latency has a whole ticket's compute time to pass and never sits in front of a load in the return queue.
+            constexpr int TB = 2;
+            const int ntick = (nfull / U + TB - 1) / TB, ngroups = nfull / U;
+            int t0 = __builtin_amdgcn_readfirstlane(draw());
+            int t1v = draw();
+            while (t0 < ntick) {
+                const int g = t0 * TB;
+                do_group(g, true);                       // draws the ticket after next into `drawn`
+                if (g + 1 < ngroups) do_group(g + 1, false);
+                t0 = __builtin_amdgcn_readfirstlane(t1v);
+                t1v = drawn;
+            }
+        } else if (il) {
+            for (int g = ks; g < nfull / U; g += KS) do_group(g, false);
         }
         // what the groups do not cover: il == 0: this split's whole range; otherwise the last columns, split 0's job
         int k = il ? nfull : k0;
@@ -189,6 +232,8 @@ __global__ void __launch_bounds__(GV_BLOCK) k_gemvN_fpe_sx(int m, int n, const d
 #pragma unroll
         for (int i = 0; i < N; ++i) o[i] = f1[i];
     }
+    if (TL && (tid & 63) == 0)
+        timeline[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * GV_WAVES + (tid >> 6)) * 2 + 1] = wall_clock64();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -302,11 +347,11 @@ __global__ void __launch_bounds__(GV_BLOCK) k_gemv_finish(int rows, int nvals, c
 // ---------------------------------------------------------------------------------------------
 // 'T': y_j = Round(sum_i A(i,j) * fl(alpha*x_i) (+) beta*y_j); column j is contiguous -> ExDOT per workgroup
 // ---------------------------------------------------------------------------------------------
-template <int N, bool EE, int COPIES, int U = 2, int ZM = 0>
-__global__ void __launch_bounds__(GV_BLOCK) k_gemvT(int m, double alpha, const double *__restrict__ a, long long lda,
+template <int N, bool EE, int COPIES, int U = 2, int ZM = 0, int MINW = 1>
+__global__ void __launch_bounds__(GV_BLOCK, MINW) k_gemvT(int m, double alpha, const double *__restrict__ a, long long lda,
                                                     const double *__restrict__ x, long long incx, double beta,
                                                     double *__restrict__ y, long long incy, int round_mode,
-                                                    int stagger)
+                                                    int stagger, long long *__restrict__ ws)
 {
     __shared__ long long s_acc[GV_WAVES * NL * COPIES];
     __shared__ long long merged[NL];
@@ -373,7 +418,7 @@ __global__ void __launch_bounds__(GV_BLOCK) k_gemvT(int m, double alpha, const d
         fpe_absorb_prod<N, false, 1>(f, p, e, sink);
     }
     fpe_flush_sink<N>(f, sink);
-    if (tid == 0 && beta != 0.0) {
+    if (ws == nullptr && tid == 0 && beta != 0.0) {
         const double yv = y[j * incy];
         if (beta == 1.0) {
             sink.add(yv);
@@ -391,7 +436,14 @@ __global__ void __launch_bounds__(GV_BLOCK) k_gemvT(int m, double alpha, const d
         for (int w = 0; w < GV_WAVES; ++w)
 #pragma unroll
             for (int c = 0; c < COPIES; ++c) sum += s_acc[(w * NL + l) * COPIES + c];
-        merged[l] = sum;
+        if (ws) ws[j * SET_WORDS + l] = sum;   // deferred (A/B variant): k_gemv_finish carries, adds beta * y and rounds
+        else merged[l] = sum;
+    }
+    if (ws) {
+        // A/B variant: the column's 68 limbs + 3 non-finite indicators go to memory and ONE k_gemv_finish launch rounds
+        // all n outputs (a wave per output, ~30 us at n = 32768)
+        if (tid < 3) ws[j * SET_WORDS + NL + tid] = (s_flags >> tid) & 1u;
+        return;
     }
     __syncthreads();
     if (wave == 0) {  // one wavefront carries, cuts and rounds (shuffles + ballots only)
@@ -445,13 +497,15 @@ static hipError_t gemvN_fpe(Ctx &c, int m, int n, double alpha, const double *a,
     const size_t ws_bytes = (size_t)m * SET_WORDS * sizeof(long long);
     const size_t part_bytes = (size_t)m * KS * N * sizeof(double);
     const size_t xa_bytes = ((size_t)n * sizeof(double) + 255) & ~(size_t)255;
+    const size_t tk_bytes = (size_t)gx * GV_WAVES * GV_TICKET_STRIDE;  // group tickets, one per 128 rows
     hipError_t e;
-    char *base = (char *)workspace(c, ws_bytes + part_bytes + xa_bytes, st, &e);
+    char *base = (char *)workspace(c, ws_bytes + tk_bytes + part_bytes + xa_bytes, st, &e);
     if (!base) return e;
     long long *ws = (long long *)base;
-    double *part = (double *)(base + ws_bytes);
-    double *xa = (double *)(base + ws_bytes + part_bytes);
-    e = hipMemsetAsync(ws, 0, ws_bytes, st);
+    int *tickets = (int *)(base + ws_bytes);
+    double *part = (double *)(base + ws_bytes + tk_bytes);
+    double *xa = (double *)(base + ws_bytes + tk_bytes + part_bytes);
+    e = hipMemsetAsync(ws, 0, ws_bytes + tk_bytes, st);  // the rows' spill accumulators and the tickets
     if (e != hipSuccess) return e;
     const bool vec = (m % 2 == 0) && (lda % 2 == 0) && (((uintptr_t)a) & 15u) == 0;
     dim3 grid(gx, KS);
@@ -459,8 +513,18 @@ static hipError_t gemvN_fpe(Ctx &c, int m, int n, double alpha, const double *a,
         // production: x from SGPRs (scalar loads of the pre-scaled vector), early-exit votes by fp64 compares.  Against
         // the LDS-staged kernel below (variant 6) in one process: 1.40-1.45 ms against 1.41-1.48 at 32768^2
         hipLaunchKernelGGL(k_scale_x, dim3((n + 255) / 256), dim3(256), 0, st, n, alpha, x, (long long)incx, xa);
-        hipLaunchKernelGGL((k_gemvN_fpe_sx<N, EE, 8>), grid, dim3(GV_BLOCK), 0, st, m, n, a, (long long)lda, xa, kper, part,
-                           ws, c.variant == 9 ? 0 : (c.variant == 10 ? 1 : 2));
+        const int il = c.variant == 9 ? 0 : (c.variant == 10 ? 1 : (c.variant == 11 ? 2 : 3));
+        bool traced = false;
+        if constexpr (N == 8 && EE) {
+            if (exblas_debug_timeline) {
+                traced = true;
+                hipLaunchKernelGGL((k_gemvN_fpe_sx<N, EE, 8, true>), grid, dim3(GV_BLOCK), 0, st, m, n, a, (long long)lda, xa,
+                                   kper, part, ws, il, tickets, (unsigned long long *)exblas_debug_timeline);
+            }
+        }
+        if (!traced)
+            hipLaunchKernelGGL((k_gemvN_fpe_sx<N, EE, 8>), grid, dim3(GV_BLOCK), 0, st, m, n, a, (long long)lda, xa, kper, part,
+                               ws, il, tickets, (unsigned long long *)nullptr);
     } else if (vec && c.variant == 1)
         hipLaunchKernelGGL((k_gemvN_fpe<N, EE, true, 4>), grid, dim3(GV_BLOCK), 0, st, m, n, alpha, a, (long long)lda, x,
                            (long long)incx, kper, part, ws);
@@ -508,15 +572,31 @@ static hipError_t gemvT(Ctx &c, int m, int n, double alpha, const double *a, int
     constexpr int COPIES = (N == 0) ? 16 : 8;
     // A/B on MI355X (tools/tune_gemv.py, 32768^2): 4 loads per stream in flight + staggered sweeps 5.3 TB/s;
     // 2 loads 5.0; no stagger 4.9; a wave-per-column form (no workgroup barriers) and a persistent form were slower
+    // Rounding inside the workgroup (production) or deferred to one k_gemv_finish launch over all n outputs (variant 12:
+    // the column's limbs go through memory).  Measured at 32768^2: 1.616 ms against 1.649 deferred -- the ~6 us single-wave
+    // carry + round chain at the end of a workgroup's 39 us life is covered by the other workgroups of the CU; the extra
+    // launch is not.
+    long long *ws = nullptr;
+    if (c.variant == 12) {
+        hipError_t e;
+        ws = (long long *)workspace(c, (size_t)n * SET_WORDS * sizeof(long long), st, &e);
+        if (!ws) return e;
+    }
     if (c.variant == 1)
         hipLaunchKernelGGL((k_gemvT<N, EE, COPIES, 2>), dim3(n), dim3(GV_BLOCK), 0, st, m, alpha, a, (long long)lda, x,
-                           (long long)incx, beta, y, (long long)incy, round_mode, 0);
+                           (long long)incx, beta, y, (long long)incy, round_mode, 0, ws);
+    else if (c.variant == 13)  // A/B: four waves per SIMD (the compiler must fit 128 registers)
+        hipLaunchKernelGGL((k_gemvT<N, EE, COPIES, 4, 1, 4>), dim3(n), dim3(GV_BLOCK), 0, st, m, alpha, a, (long long)lda, x,
+                           (long long)incx, beta, y, (long long)incy, round_mode, 1, ws);
     else if (c.variant == 6)  // A/B: early-exit votes by integer ORs of the residue words
         hipLaunchKernelGGL((k_gemvT<N, EE, COPIES, 4>), dim3(n), dim3(GV_BLOCK), 0, st, m, alpha, a, (long long)lda, x,
-                           (long long)incx, beta, y, (long long)incy, round_mode, 1);
+                           (long long)incx, beta, y, (long long)incy, round_mode, 1, ws);
     else  // early-exit votes by fp64 compares: 1.58-1.61 ms against 1.64-1.66 at 32768^2
         hipLaunchKernelGGL((k_gemvT<N, EE, COPIES, 4, 1>), dim3(n), dim3(GV_BLOCK), 0, st, m, alpha, a, (long long)lda, x,
-                           (long long)incx, beta, y, (long long)incy, round_mode, 1);
+                           (long long)incx, beta, y, (long long)incy, round_mode, 1, ws);
+    if (ws)
+        hipLaunchKernelGGL(k_gemv_finish, dim3((n + GV_WAVES - 1) / GV_WAVES), dim3(GV_BLOCK), 0, st, n, 0,
+                           (const double *)nullptr, ws, beta, y, (long long)incy, round_mode);
     return hipGetLastError();
 }
 
@@ -567,3 +647,12 @@ hipError_t exgemv_dispatch(Ctx &c, char transa, int m, int n, double alpha, cons
 }
 
 }  // namespace exb
+
+// tools/ only: what the occupancy API says for the production 'N' kernel (blocks of 256 threads per CU)
+extern "C" int exblas_debug_gemv_occupancy(void)
+{
+    int nb = -1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, exb::k_gemvN_fpe_sx<8, true, 8, false>, exb::GV_BLOCK, 0) != hipSuccess)
+        return -1;
+    return nb;
+}
