@@ -318,9 +318,17 @@ def bench_blas23(ex, torch, comm, world, rank):
     reference test, tests/test.exgemm.gpu.cpp:183-184).  N > 1 reports two timings: `ms` = the row-sharded product with
     C left sharded (B already on every rank: no collective at all) and `ms_gathered` = B broadcast from rank 0 + the
     product + in-place all-gather of C inside exblas_exgemm_sharded_dev."""
-    def timeit(fn, reps):
+    def timeit(fn, reps, prewarm_ms=250.0):
+        # the same policy as the headline's --prewarm-ms: the chip needs a few hundred ms of load to reach its sustained
+        # clocks, and each item here starts after an idle gap (allocation, generation, host work) -- measured with
+        # tools/gemv_ctx.py: the first 11 calls after such a gap run 1.52 ms, every later batch 1.34-1.39
         fn()
         torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        while (time.perf_counter() - t0) * 1e3 < prewarm_ms:
+            for _ in range(5):
+                fn()
+            torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
@@ -338,7 +346,7 @@ def bench_blas23(ex, torch, comm, world, rank):
           "bytes": 8.0 * (m * n + n + 2 * m)}
     gv["ms"] = timeit(lambda: ex.exgemv_dev("N", m, n, 1.0, a, m, x, 1.0, y, 8, True), 10)
     gv["ms_T"] = timeit(lambda: ex.exgemv_dev("T", m, n, 1.0, a, m, x, 1.0, y, 8, True), 10)
-    gv["ms_superacc_only"] = timeit(lambda: ex.exgemv_dev("N", m, n, 1.0, a, m, x, 1.0, y, 0, False), 3)
+    gv["ms_superacc_only"] = timeit(lambda: ex.exgemv_dev("N", m, n, 1.0, a, m, x, 1.0, y, 0, False), 3, 50.0)
     # ExTRSV on the same matrix storage (lower triangle of a, made diagonally dominant): latency-bound, replicas
     # for N > 1 (the substitution does not shard)
     d = ex.gen_dev("fpuniform", n, 16, 1.0, 17.0)        # diagonal entries in [2^16, 2^17): dominates 32767 entries < 1
@@ -349,7 +357,7 @@ def bench_blas23(ex, torch, comm, world, rank):
     def solve():
         xs.copy_(b)
         ex.extrsv_dev("L", "N", "N", n, a, n, xs, 8, True)
-    ms = timeit(solve, 3)
+    ms = timeit(solve, 3, 0.0)
     tv = {"workload": "ExTRSV 'L','N','N' n=32768 fp64 column-major, fpe=8 early_exit, per GPU", "ms": ms,
           "us_per_row": ms * 1e3 / n, "n2_per_s_G": n * float(n) / (ms * 1e-3) / 1e9,
           "bound": "latency: one dependency chain of n rounded divisions (DESIGN.md 5a)",
@@ -372,6 +380,8 @@ def bench_blas23(ex, torch, comm, world, rank):
     def timed_gemm(gather, reps=3):
         # beta = 1 updates C in place: every timed call starts from the same C0 (the copy is outside the events)
         tot = 0.0
+        for _ in range(12):                      # ~150 ms of untimed load first (see timeit)
+            gemm(gather)
         for it in range(reps + 1):
             C.copy_(C0)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -347,9 +347,10 @@ __global__ void __launch_bounds__(GV_BLOCK) k_gemv_finish(int rows, int nvals, c
 // ---------------------------------------------------------------------------------------------
 // 'T': y_j = Round(sum_i A(i,j) * fl(alpha*x_i) (+) beta*y_j); column j is contiguous -> ExDOT per workgroup
 // ---------------------------------------------------------------------------------------------
+// x: the pre-scaled contiguous vector x' = fl(alpha * x) (k_scale_x), so the kernel carries neither the multiply nor incx
 template <int N, bool EE, int COPIES, int U = 2, int ZM = 0, int MINW = 1>
-__global__ void __launch_bounds__(GV_BLOCK, MINW) k_gemvT(int m, double alpha, const double *__restrict__ a, long long lda,
-                                                    const double *__restrict__ x, long long incx, double beta,
+__global__ void __launch_bounds__(GV_BLOCK, MINW) k_gemvT(int m, const double *__restrict__ a, long long lda,
+                                                    const double *__restrict__ x, double beta,
                                                     double *__restrict__ y, long long incy, int round_mode,
                                                     int stagger, long long *__restrict__ ws)
 {
@@ -368,7 +369,7 @@ __global__ void __launch_bounds__(GV_BLOCK, MINW) k_gemvT(int m, double alpha, c
 #pragma unroll
     for (int i = 0; i < (N > 0 ? N : 1); ++i) f[i] = 0.0;
 
-    const bool vec = incx == 1 && ((((uintptr_t)col) | ((uintptr_t)x)) & 15u) == 0;
+    const bool vec = ((((uintptr_t)col) | ((uintptr_t)x)) & 15u) == 0;
     long long done = 0;
     Bypass bypass;
     if (vec) {
@@ -378,25 +379,29 @@ __global__ void __launch_bounds__(GV_BLOCK, MINW) k_gemvT(int m, double alpha, c
         // workgroup starts its sweep at a different tile (and wraps) so that concurrent columns spread over the
         // channels instead of marching through them in lockstep.
         const long long t0 = stagger ? (j * 37) % (ntiles > 0 ? ntiles : 1) : 0;
+        // a wave owns U KiB of the tile and each of its loads covers 1 KiB of it: the U loads of a lane are 1 KiB apart,
+        // i.e. ONE address register pair + immediate offsets (they were 4 KiB apart, beyond the 12-bit offset: a 64-bit
+        // add per load)
+        const int lane_off = (tid >> 6) * (64 * U) + (tid & 63);
         if (ntiles > 0) {
             // two register sets filled alternately with unconditional loads (see k_exdot in blas1.hip)
             d2_t ra[U], rx[U], rb[U], ry[U];
             auto fill = [&](long long tt, d2_t (&qa)[U], d2_t (&qx)[U]) {
                 long long t = (tt < ntiles ? tt : ntiles - 1) + t0;
                 if (t >= ntiles) t -= ntiles;
-                const long long base = t * tile + tid;
+                const long long base = t * tile + lane_off;
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    qa[u] = ld2<true>(va + base + u * GV_BLOCK);
-                    qx[u] = vx[base + u * GV_BLOCK];  // x is re-read by every workgroup: keep it cacheable
+                    qa[u] = ld2<true>(va + base + u * 64);
+                    qx[u] = vx[base + u * 64];  // x is re-read by every workgroup: keep it cacheable
                 }
             };
             auto absorb = [&](d2_t (&qa)[U], d2_t (&qx)[U]) {
                 double p[2 * U], e[2 * U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    p[2 * u] = two_prod(qa[u].x, alpha * qx[u].x, e[2 * u]);
-                    p[2 * u + 1] = two_prod(qa[u].y, alpha * qx[u].y, e[2 * u + 1]);
+                    p[2 * u] = two_prod(qa[u].x, qx[u].x, e[2 * u]);
+                    p[2 * u + 1] = two_prod(qa[u].y, qx[u].y, e[2 * u + 1]);
                 }
                 fpe_absorb_prod_adaptive<N, EE, 2 * U, LdsSink<COPIES>, ZM>(f, p, e, sink, bypass);
             };
@@ -414,7 +419,7 @@ __global__ void __launch_bounds__(GV_BLOCK, MINW) k_gemvT(int m, double alpha, c
     }
     for (long long i = done + tid; i < m; i += GV_BLOCK) {
         double p[1], e[1];
-        p[0] = two_prod(col[i], alpha * x[i * incx], e[0]);
+        p[0] = two_prod(col[i], x[i], e[0]);
         fpe_absorb_prod<N, false, 1>(f, p, e, sink);
     }
     fpe_flush_sink<N>(f, sink);
@@ -577,23 +582,25 @@ static hipError_t gemvT(Ctx &c, int m, int n, double alpha, const double *a, int
     // carry + round chain at the end of a workgroup's 39 us life is covered by the other workgroups of the CU; the extra
     // launch is not.
     long long *ws = nullptr;
-    if (c.variant == 12) {
+    // x' = fl(alpha * x), contiguous, once (m doubles behind the deferred-finish area of the workspace)
+    const size_t ws_bytes = c.variant == 12 ? (size_t)n * SET_WORDS * sizeof(long long) : 0;
+    {
         hipError_t e;
-        ws = (long long *)workspace(c, (size_t)n * SET_WORDS * sizeof(long long), st, &e);
-        if (!ws) return e;
+        char *base = (char *)workspace(c, ws_bytes + (size_t)m * sizeof(double), st, &e);
+        if (!base) return e;
+        if (ws_bytes) ws = (long long *)base;
+        double *xa = (double *)(base + ws_bytes);
+        hipLaunchKernelGGL(k_scale_x, dim3((m + 255) / 256), dim3(256), 0, st, m, alpha, x, (long long)incx, xa);
+        x = xa;
     }
-    if (c.variant == 1)
-        hipLaunchKernelGGL((k_gemvT<N, EE, COPIES, 2>), dim3(n), dim3(GV_BLOCK), 0, st, m, alpha, a, (long long)lda, x,
-                           (long long)incx, beta, y, (long long)incy, round_mode, 0, ws);
-    else if (c.variant == 13)  // A/B: four waves per SIMD (the compiler must fit 128 registers)
-        hipLaunchKernelGGL((k_gemvT<N, EE, COPIES, 4, 1, 4>), dim3(n), dim3(GV_BLOCK), 0, st, m, alpha, a, (long long)lda, x,
-                           (long long)incx, beta, y, (long long)incy, round_mode, 1, ws);
-    else if (c.variant == 6)  // A/B: early-exit votes by integer ORs of the residue words
-        hipLaunchKernelGGL((k_gemvT<N, EE, COPIES, 4>), dim3(n), dim3(GV_BLOCK), 0, st, m, alpha, a, (long long)lda, x,
-                           (long long)incx, beta, y, (long long)incy, round_mode, 1, ws);
-    else  // early-exit votes by fp64 compares: 1.58-1.61 ms against 1.64-1.66 at 32768^2
-        hipLaunchKernelGGL((k_gemvT<N, EE, COPIES, 4, 1>), dim3(n), dim3(GV_BLOCK), 0, st, m, alpha, a, (long long)lda, x,
-                           (long long)incx, beta, y, (long long)incy, round_mode, 1, ws);
+#define GVT_LAUNCH(...)                                                                                                \
+    hipLaunchKernelGGL((k_gemvT<N, EE, COPIES, __VA_ARGS__>), dim3(n), dim3(GV_BLOCK), 0, st, m, a, (long long)lda, x, \
+                       beta, y, (long long)incy, round_mode, c.variant == 1 ? 0 : 1, ws)
+    if (c.variant == 1) GVT_LAUNCH(2);             // two loads per stream in flight, no stagger
+    else if (c.variant == 13) GVT_LAUNCH(4, 1, 4); // A/B: four waves per SIMD (the compiler must fit 128 registers: it spills)
+    else if (c.variant == 6) GVT_LAUNCH(4);        // A/B: early-exit votes by integer ORs of the residue words
+    else GVT_LAUNCH(4, 1);                         // early-exit votes by fp64 compares: 1.58-1.61 ms against 1.64-1.66 at 32768^2
+#undef GVT_LAUNCH
     if (ws)
         hipLaunchKernelGGL(k_gemv_finish, dim3((n + GV_WAVES - 1) / GV_WAVES), dim3(GV_BLOCK), 0, st, n, 0,
                            (const double *)nullptr, ws, beta, y, (long long)incy, round_mode);

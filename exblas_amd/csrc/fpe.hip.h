@@ -78,32 +78,33 @@ struct GlobalSink {
 
 // ---- the cascade -----------------------------------------------------------------------------
 // Range guard (one wave-uniform test per tile): TwoSum is only error-free while a + x stays finite.
-// Elements of magnitude >= 2^1000 and Inf/NaN bypass the expansion and go straight to the integer
-// accumulator (which holds them exactly, resp. classifies them), and a[0] is spilled once it reaches
-// 2^1000 -- so a[0] never exceeds (1 + CNT) * 2^1000 and cannot overflow.  The reference has no such
-// guard (ExSUM.FPE.hpp:408 "TODO ... Inf/Overflow/NaN").  `e` (optional): the TwoProd error terms that
-// belong to x; the error term of a non-finite product is meaningless (fma(a,b,-inf)) and is zeroed here.
+// When any lane of the wave holds an element of magnitude >= 2^1000 (or Inf/NaN), or an a[0] that has reached
+// 2^1000, the WHOLE tile of every lane bypasses the expansion and goes straight to the integer accumulator
+// (which holds any double exactly, resp. classifies Inf/NaN), and such an a[0] is spilled -- so a[0] never
+// exceeds (1 + CNT) * 2^1000 and cannot overflow.  The reference has no such guard (ExSUM.FPE.hpp:408
+// "TODO ... Inf/Overflow/NaN").  `e` (optional): the TwoProd error terms that belong to x; the error term of a
+// non-finite product is meaningless (fma(a,b,-inf)) and is dropped.
+// Diverting the tile as a whole (instead of zeroing only the big elements in place, as this routine first did)
+// leaves x / e untouched on the hot path: no merged values after the branch, i.e. none of the register copies
+// the in-place form cost (17 v_mov_b64 + 8 repeated v_bfe per 8-element tile in k_gemvT).
+// Returns (wave-uniform) true when the tile was diverted.
 template <int CNT, class Sink>
-__device__ __forceinline__ void fpe_guard(double &a0, double (&x)[CNT], double *e, Sink &sink)
+__device__ __forceinline__ bool fpe_guard(double &a0, const double (&x)[CNT], const double *e, Sink &sink)
 {
     unsigned mx = expo_field(a0);
 #pragma unroll
     for (int j = 0; j < CNT; ++j) mx = max(mx, expo_field(x[j]));
-    if (__any(mx >= BIG_EXPO)) {
+    if (!__any(mx >= BIG_EXPO)) return false;
 #pragma unroll
-        for (int j = 0; j < CNT; ++j) {
-            const unsigned ex = expo_field(x[j]);
-            if (ex >= BIG_EXPO) {
-                sink.add(x[j]);
-                x[j] = 0.0;
-                if (e && ex == 0x7ffu) e[j] = 0.0;
-            }
-        }
-        if (expo_field(a0) >= BIG_EXPO) {
-            sink.add(a0);
-            a0 = 0.0;
-        }
+    for (int j = 0; j < CNT; ++j) {
+        sink.add(x[j]);
+        if (e && e[j] != 0.0 && expo_field(x[j]) != 0x7ffu) sink.add(e[j]);
     }
+    if (expo_field(a0) >= BIG_EXPO) {
+        sink.add(a0);
+        a0 = 0.0;
+    }
+    return true;
 }
 
 // Push CNT elements (a "tile") through expansion levels from..N-1.  EE: one wave-uniform test per
@@ -143,7 +144,7 @@ __device__ __forceinline__ bool fpe_absorb_sink(double (&a)[N > 0 ? N : 1], doub
         for (int j = 0; j < CNT; ++j) sink.add(x[j]);
         return false;
     } else {
-        if (from == 0) fpe_guard<CNT>(a[0], x, nullptr, sink);
+        if (from == 0 && fpe_guard<CNT>(a[0], x, nullptr, sink)) return true;
         return fpe_cascade<N, EE, CNT, Sink, ZM>(a, x, from, sink);
     }
 }
@@ -198,7 +199,7 @@ __device__ __forceinline__ bool fpe_absorb_prod(double (&a)[N > 0 ? N : 1], doub
         return false;
     } else {
         constexpr int EFROM = (N >= 3) ? N - 3 : 0;
-        fpe_guard<CNT>(a[0], p, e, sink);
+        if (fpe_guard<CNT>(a[0], p, e, sink)) return true;
         const bool s1 = fpe_cascade<N, EE, CNT, Sink, ZM>(a, p, 0, sink);
         const bool s2 = fpe_cascade<N, EE, CNT, Sink, ZM>(a, e, EFROM, sink);
         return s1 || s2;
