@@ -38,6 +38,9 @@ C_ABI_SYMBOLS = [
     "exblas_exgemv_sharded_dev", "exblas_exgemm_sharded_dev", "exblas_last_gemm_info", "exblas_set_gemm_max_slices",
     "exblas_set_gemm_max_moduli", "exblas_crt_selftest",
     "exblas_set_host_devices", "exblas_workspace_bytes",
+    "exblas_ctx_create", "exblas_ctx_destroy", "exblas_exsum_ctx", "exblas_exdot_ctx", "exblas_exsum_accumulate_ctx",
+    "exblas_exdot_accumulate_ctx", "exblas_finish_ctx", "exblas_exgemv_ctx", "exblas_extrsv_ctx", "exblas_exgemm_ctx",
+    "exblas_reserve_workspace_ctx", "exblas_workspace_bytes_ctx", "exblas_last_gemm_info_ctx",
 ]
 
 # host-transport callback types of include/exblas_hip.h
@@ -114,6 +117,20 @@ def load_library():
     L.exblas_exgemm.argtypes = [C.c_char, C.c_char, i32, i32, i32, dbl, vp, i32, vp, i32, dbl, vp, i32, i32, i32]
     L.exblas_reserve_workspace.argtypes = [C.c_size_t]
     L.exblas_workspace_bytes.restype = C.c_size_t
+    L.exblas_ctx_create.argtypes = [C.POINTER(vp)]
+    L.exblas_ctx_destroy.argtypes = [vp]
+    L.exblas_exsum_ctx.argtypes = [vp] + L.exblas_exsum_dev.argtypes
+    L.exblas_exdot_ctx.argtypes = [vp] + L.exblas_exdot_dev.argtypes
+    L.exblas_exsum_accumulate_ctx.argtypes = [vp] + L.exblas_exsum_accumulate_dev.argtypes
+    L.exblas_exdot_accumulate_ctx.argtypes = [vp] + L.exblas_exdot_accumulate_dev.argtypes
+    L.exblas_finish_ctx.argtypes = [vp] + L.exblas_finish_dev.argtypes
+    L.exblas_exgemv_ctx.argtypes = [vp] + L.exblas_exgemv_dev.argtypes
+    L.exblas_extrsv_ctx.argtypes = [vp] + L.exblas_extrsv_dev.argtypes
+    L.exblas_exgemm_ctx.argtypes = [vp] + L.exblas_exgemm_dev.argtypes
+    L.exblas_reserve_workspace_ctx.argtypes = [vp, C.c_size_t]
+    L.exblas_workspace_bytes_ctx.argtypes = [vp]
+    L.exblas_workspace_bytes_ctx.restype = C.c_size_t
+    L.exblas_last_gemm_info_ctx.argtypes = [vp, C.POINTER(C.c_int)]
     L.exblas_set_host_devices.argtypes = [i32, C.POINTER(C.c_int)]
     L.exblas_last_gemm_info.argtypes = [C.POINTER(C.c_int)]
     L.exblas_set_gemm_max_slices.argtypes = [i32]
@@ -301,6 +318,88 @@ def exgemm_dev(transa, transb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, fpe
                                             C.c_void_p(c.data_ptr()), ldc, fpe, int(early_exit), _stream_ptr(torch)),
            "exgemm_dev")
     return c
+
+
+class Context:
+    """Owner of an ``exblas_ctx_t *``: private accumulators, flags and workspace on the current device, so that work
+    enqueued through different contexts (on different streams) needs no ordering.  Methods mirror the ``*_dev``
+    functions; tensors are CUDA float64 / int64 on the context's device, calls go to the CURRENT torch stream."""
+
+    def __init__(self):
+        _require_gpu()
+        h = C.c_void_p()
+        _check(load_library().exblas_ctx_create(C.byref(h)), "ctx_create")
+        self.handle = h
+
+    def destroy(self):
+        if self.handle is not None:
+            load_library().exblas_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def exsum(self, x, fpe=8, early_exit=True, inca=1, n=None, out=None):
+        torch = _require_gpu()
+        if n is None:
+            n = (x.numel() + inca - 1) // inca
+        if out is None:
+            out = new_record_buffer()
+        _check(load_library().exblas_exsum_ctx(self.handle, C.c_void_p(x.data_ptr()), n, inca, fpe, int(early_exit),
+                                               _stream_ptr(torch), C.c_void_p(out.data_ptr())), "exsum_ctx")
+        return out
+
+    def exdot(self, x, y, fpe=8, early_exit=True, out=None):
+        torch = _require_gpu()
+        if out is None:
+            out = new_record_buffer()
+        _check(load_library().exblas_exdot_ctx(self.handle, C.c_void_p(x.data_ptr()), 1, C.c_void_p(y.data_ptr()), 1,
+                                               x.numel(), fpe, int(early_exit), _stream_ptr(torch),
+                                               C.c_void_p(out.data_ptr())), "exdot_ctx")
+        return out
+
+    def exsum_accumulate(self, x, fpe=8, early_exit=True):
+        torch = _require_gpu()
+        _check(load_library().exblas_exsum_accumulate_ctx(self.handle, C.c_void_p(x.data_ptr()), x.numel(), 1, fpe,
+                                                          int(early_exit), _stream_ptr(torch)), "exsum_accumulate_ctx")
+
+    def finish(self, out=None):
+        torch = _require_gpu()
+        if out is None:
+            out = new_record_buffer()
+        _check(load_library().exblas_finish_ctx(self.handle, _stream_ptr(torch), C.c_void_p(out.data_ptr())),
+               "finish_ctx")
+        return out
+
+    def exgemv(self, trans, m, n, alpha, a, lda, x, beta, y, fpe=0, early_exit=False, incx=1, incy=1):
+        torch = _require_gpu()
+        _check(load_library().exblas_exgemv_ctx(self.handle, trans.encode(), m, n, alpha, C.c_void_p(a.data_ptr()), lda,
+                                                C.c_void_p(x.data_ptr()), incx, beta, C.c_void_p(y.data_ptr()), incy,
+                                                fpe, int(early_exit), _stream_ptr(torch)), "exgemv_ctx")
+        return y
+
+    def exgemm(self, transa, transb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, fpe=0, early_exit=False):
+        torch = _require_gpu()
+        _check(load_library().exblas_exgemm_ctx(self.handle, transa.encode(), transb.encode(), m, n, k, alpha,
+                                                C.c_void_p(a.data_ptr()), lda, C.c_void_p(b.data_ptr()), ldb, beta,
+                                                C.c_void_p(c.data_ptr()), ldc, fpe, int(early_exit),
+                                                _stream_ptr(torch)), "exgemm_ctx")
+        return c
+
+    def extrsv(self, uplo, trans, diag, n, a, lda, x, fpe=0, early_exit=False, incx=1):
+        torch = _require_gpu()
+        rc = load_library().exblas_extrsv_ctx(self.handle, uplo.encode(), trans.encode(), diag.encode(), n,
+                                              C.c_void_p(a.data_ptr()), lda, C.c_void_p(x.data_ptr()), incx, fpe,
+                                              int(early_exit), _stream_ptr(torch))
+        if rc != -1:
+            _check(rc, "extrsv_ctx")
+        return rc
+
+    def workspace_bytes(self):
+        return load_library().exblas_workspace_bytes_ctx(self.handle)
 
 
 def gen_dev(kind, n, seed=1, p0=0.0, p1=0.0, first=0, count=None, n_total=None, out=None):

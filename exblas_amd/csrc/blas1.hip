@@ -229,6 +229,7 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_exdot(const double *__restrict__
                 x[2 * u] = two_prod(ra[u].x, rb[u].x, e[2 * u]);
                 x[2 * u + 1] = two_prod(ra[u].y, rb[u].y, e[2 * u + 1]);
             }
+            prod_underflow_note<2 * U>(x, flags, [&](int j) { return (j & 1 ? ra[j >> 1].y : ra[j >> 1].x) != 0.0 && (j & 1 ? rb[j >> 1].y : rb[j >> 1].x) != 0.0; });
             fpe_absorb_prod_adaptive<N, EE, 2 * U>(fpe, x, e, sink, bypass);
         }
     } else {
@@ -256,6 +257,7 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_exdot(const double *__restrict__
                         x[2 * u] = two_prod(ra[h * H + u].x, rb[h * H + u].x, e[2 * u]);
                         x[2 * u + 1] = two_prod(ra[h * H + u].y, rb[h * H + u].y, e[2 * u + 1]);
                     }
+                    prod_underflow_note<2 * H>(x, flags, [&](int j) { return (j & 1 ? ra[h * H + (j >> 1)].y : ra[h * H + (j >> 1)].x) != 0.0 && (j & 1 ? rb[h * H + (j >> 1)].y : rb[h * H + (j >> 1)].x) != 0.0; });
                     if (tn < ntiles) {
                         const long long base = tn * TILE + threadIdx.x;
 #pragma unroll
@@ -288,6 +290,7 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_exdot(const double *__restrict__
                     x[2 * u] = two_prod(pa[u].x, pb[u].x, e[2 * u]);
                     x[2 * u + 1] = two_prod(pa[u].y, pb[u].y, e[2 * u + 1]);
                 }
+                prod_underflow_note<2 * U>(x, flags, [&](int j) { return (j & 1 ? pa[j >> 1].y : pa[j >> 1].x) != 0.0 && (j & 1 ? pb[j >> 1].y : pb[j >> 1].x) != 0.0; });
                 fpe_absorb_prod_adaptive<N, EE, 2 * U, LdsSink<COPIES>, ZM>(fpe, x, e, sink, bypass);
             };
             for (;;) {
@@ -308,10 +311,13 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_exdot(const double *__restrict__
         double x[2], e[2];
         x[0] = two_prod(ra.x, rb.x, e[0]);
         x[1] = two_prod(ra.y, rb.y, e[1]);
+        prod_underflow_note<2>(x, flags, [&](int j) { return (j ? ra.y : ra.x) != 0.0 && (j ? rb.y : rb.x) != 0.0; });
         fpe_absorb_prod<N, false, 2>(fpe, x, e, sink);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0 && (n & 1)) {
         double e, p = two_prod_safe(a[n - 1], b[n - 1], e);
+        if (expo_field(p) < LOW_EXPO && a[n - 1] != 0.0 && b[n - 1] != 0.0) flags |= FLAG_PUNDER;
+        if (__builtin_isinf(p) && __builtin_isfinite(a[n - 1]) && __builtin_isfinite(b[n - 1])) flags |= FLAG_POVER;
         lds_add<COPIES>(col, p, flags);
         lds_add<COPIES>(col, e, flags);  // e == 0 when p overflowed (two_prod_safe)
     }
@@ -346,6 +352,7 @@ __global__ void __launch_bounds__(BLOCK) k_exdot_strided(const double *__restric
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) x[u] = two_prod(va[u], vb[u], e[u]);
+        prod_underflow_note<4>(x, flags, [&](int j) { return va[j] != 0.0 && vb[j] != 0.0; });
         fpe_absorb_prod<N, false, 4>(fpe, x, e, sink);
     }
     fpe_flush<N, COPIES>(fpe, col, flags);
@@ -365,8 +372,13 @@ __global__ void __launch_bounds__(64) k_finalize(long long *sets, int nsets, int
     if (gflags) flags |= *gflags;
     if (set_stride >= SET_WORDS) {  // record-style sets carry their own flag indicators
         for (int g = 0; g < nsets; ++g)
+        {
             for (int k = 0; k < 3; ++k)
                 if (sets[(size_t)g * set_stride + NL + k] != 0) flags |= (1u << k);
+            const long long pw = sets[(size_t)g * set_stride + NL + 3];  // product flags: low 16 bits / the rest
+            if (pw & 0xffff) flags |= FLAG_PUNDER;
+            if (pw >> 16) flags |= FLAG_POVER;
+        }
     }
     // all loads of a batch are issued before the first use (the words were last touched by other CUs' atomics,
     // so each load is a full memory round trip: 32 dependent ones cost ~20 us)

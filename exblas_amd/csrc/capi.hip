@@ -69,6 +69,53 @@ static int current_device()
     return d < MAX_DEV ? d : 0;
 }
 
+// creates the device objects of a context (accumulators, flags, record buffers, stream) on `device`; knobs come from the
+// environment, then from the device's layer-0 context when that exists (what the API has set so far)
+static void init_ctx(Ctx &c, int device, int layer)
+{
+    c.layer = layer;
+    int prev = 0;
+    EXB_CHECK(hipGetDevice(&prev));
+    EXB_CHECK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    EXB_CHECK(hipGetDeviceProperties(&prop, device));
+    c.num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    c.blocks_per_cu = env_int("EXBLAS_BLOCKS_PER_CU", 8);
+    c.bpc_sum = env_int("EXBLAS_BPC_SUM", 2);
+    c.bpc_dot = env_int("EXBLAS_BPC_DOT", 48);
+    c.bpc_sa = env_int("EXBLAS_BPC_SA", 3);
+    c.bpc_heavy = env_int("EXBLAS_BPC_HEAVY", 4);
+    c.ngroups = env_int("EXBLAS_NGROUPS", 32);
+    c.grid_adj = env_int("EXBLAS_GRID_ADJ", 0);
+    if (c.ngroups < 1) c.ngroups = 1;
+    c.variant = env_int("EXBLAS_VARIANT", 0);
+    c.gemm_path = env_int("EXBLAS_GEMM_PATH", 0);
+    if (layer > 0 && g_ctx[0][device].device >= 0) {  // knobs set through the API so far apply to every layer
+        const Ctx &z = g_ctx[0][device];
+        c.blocks_per_cu = z.blocks_per_cu; c.bpc_sum = z.bpc_sum; c.bpc_dot = z.bpc_dot; c.bpc_sa = z.bpc_sa;
+        c.bpc_heavy = z.bpc_heavy;
+        c.grid_adj = z.grid_adj;
+        c.ngroups = z.ngroups; c.variant = z.variant; c.gemm_path = z.gemm_path;
+        c.gemm_max_slices = z.gemm_max_slices;
+        c.gemm_max_moduli = z.gemm_max_moduli;
+    }
+    EXB_CHECK(crt_tables_upload());
+    EXB_CHECK(hipMalloc(&c.gacc_all, 2 * sizeof(long long) * NL * c.ngroups));
+    EXB_CHECK(hipMemset(c.gacc_all, 0, 2 * sizeof(long long) * NL * c.ngroups));
+    EXB_CHECK(hipMalloc(&c.gflags_all, 128));
+    EXB_CHECK(hipMemset(c.gflags_all, 0, 128));
+    c.gacc = c.gacc_all;
+    c.gflags = c.gflags_all;
+    c.slot = 0;
+    EXB_CHECK(hipMalloc(&c.d_record, sizeof(long long) * OUT_WORDS));
+    // portable: the record of one device's part is copied to the first device when a host call spans several
+    EXB_CHECK(hipHostMalloc(&c.h_record, sizeof(long long) * OUT_WORDS, hipHostMallocPortable));
+    EXB_CHECK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    EXB_CHECK(hipDeviceSynchronize());
+    EXB_CHECK(hipSetDevice(prev));
+    c.device = device;
+}
+
 Ctx &ctx(int device, int layer)
 {
     if (device < 0) {
@@ -86,49 +133,7 @@ Ctx &ctx(int device, int layer)
     if (layer < 0 || layer >= MAX_LAYERS) layer = 0;
     Ctx &c = g_ctx[layer][device];
     std::lock_guard<std::mutex> lk(g_ctx_mu);
-    if (c.device < 0) {
-        c.layer = layer;
-        int prev = 0;
-        EXB_CHECK(hipGetDevice(&prev));
-        EXB_CHECK(hipSetDevice(device));
-        hipDeviceProp_t prop;
-        EXB_CHECK(hipGetDeviceProperties(&prop, device));
-        c.num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        c.blocks_per_cu = env_int("EXBLAS_BLOCKS_PER_CU", 8);
-        c.bpc_sum = env_int("EXBLAS_BPC_SUM", 2);
-        c.bpc_dot = env_int("EXBLAS_BPC_DOT", 48);
-        c.bpc_sa = env_int("EXBLAS_BPC_SA", 3);
-        c.bpc_heavy = env_int("EXBLAS_BPC_HEAVY", 4);
-        c.ngroups = env_int("EXBLAS_NGROUPS", 32);
-        c.grid_adj = env_int("EXBLAS_GRID_ADJ", 0);
-        if (c.ngroups < 1) c.ngroups = 1;
-        c.variant = env_int("EXBLAS_VARIANT", 0);
-        c.gemm_path = env_int("EXBLAS_GEMM_PATH", 0);
-        if (layer > 0 && g_ctx[0][device].device >= 0) {  // knobs set through the API so far apply to every layer
-            const Ctx &z = g_ctx[0][device];
-            c.blocks_per_cu = z.blocks_per_cu; c.bpc_sum = z.bpc_sum; c.bpc_dot = z.bpc_dot; c.bpc_sa = z.bpc_sa;
-            c.bpc_heavy = z.bpc_heavy;
-            c.grid_adj = z.grid_adj;
-            c.ngroups = z.ngroups; c.variant = z.variant; c.gemm_path = z.gemm_path;
-            c.gemm_max_slices = z.gemm_max_slices;
-            c.gemm_max_moduli = z.gemm_max_moduli;
-        }
-        EXB_CHECK(crt_tables_upload());
-        EXB_CHECK(hipMalloc(&c.gacc_all, 2 * sizeof(long long) * NL * c.ngroups));
-        EXB_CHECK(hipMemset(c.gacc_all, 0, 2 * sizeof(long long) * NL * c.ngroups));
-        EXB_CHECK(hipMalloc(&c.gflags_all, 128));
-        EXB_CHECK(hipMemset(c.gflags_all, 0, 128));
-        c.gacc = c.gacc_all;
-        c.gflags = c.gflags_all;
-        c.slot = 0;
-        EXB_CHECK(hipMalloc(&c.d_record, sizeof(long long) * OUT_WORDS));
-        // portable: the record of one device's part is copied to the first device when a host call spans several
-        EXB_CHECK(hipHostMalloc(&c.h_record, sizeof(long long) * OUT_WORDS, hipHostMallocPortable));
-        EXB_CHECK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
-        EXB_CHECK(hipDeviceSynchronize());
-        EXB_CHECK(hipSetDevice(prev));
-        c.device = device;
-    }
+    if (c.device < 0) init_ctx(c, device, layer);
     return c;
 }
 
@@ -370,9 +375,8 @@ int exblas_set_accumulator_slot(int slot)
 // out[0] = implementation of the most recent exgemm on this device (0 scalar kernel, 1 fp64 slices on MFMA-F64,
 // 2 int8 slices on the int8 matrix cores), out[1] / out[2] = digits (slices) of A / B, out[3..7] reserved.
 // The int8 path decides on the device: this call then synchronises the device and reads the decision back.
-int exblas_last_gemm_info(int *out)
+static int last_gemm_info_on(Ctx &c, int *out)
 {
-    Ctx &c = ctx(-1, g_last_layer[current_device()]);
     std::lock_guard<std::mutex> lk(c.mu);
     for (int i = 0; i < 8; ++i) out[i] = 0;
     if (c.gemm_info_dev) {
@@ -395,6 +399,8 @@ int exblas_last_gemm_info(int *out)
     }
     return 0;
 }
+
+int exblas_last_gemm_info(int *out) { return last_gemm_info_on(ctx(-1, g_last_layer[current_device()]), out); }
 
 int exblas_last_gemm_slices(void)
 {
@@ -462,7 +468,7 @@ static int exgemv_on(Ctx &c, char transa, int m, int n, double alpha, const doub
 {
     if (fpe < 0) return (int)hipErrorInvalidValue;
     std::lock_guard<std::mutex> lk(c.mu);
-    g_last_layer[c.device] = c.layer;
+    if (c.layer < MAX_LAYERS) g_last_layer[c.device] = c.layer;
     return (int)exgemv_dispatch(c, transa, m, n, alpha, d_a, lda, d_x, incx, beta, d_y, incy, fpe, early_exit,
                                 round_mode(), st);
 }
@@ -474,7 +480,7 @@ static int extrsv_on(Ctx &c, char uplo, char transa, char diag, int n, const dou
     if (fpe >= 9) return EXBLAS_UNSUPPORTED;
     if (n > 0 && (lda < n || incx <= 0)) return (int)hipErrorInvalidValue;
     std::lock_guard<std::mutex> lk(c.mu);
-    g_last_layer[c.device] = c.layer;
+    if (c.layer < MAX_LAYERS) g_last_layer[c.device] = c.layer;
     return (int)extrsv_dispatch(c, uplo, transa, diag, n, d_a, lda, d_x, incx, fpe, early_exit, round_mode(), st);
 }
 
@@ -484,7 +490,7 @@ static int exgemm_on(Ctx &c, char transa, char transb, int m, int n, int k, doub
 {
     if (fpe < 0) return (int)hipErrorInvalidValue;
     std::lock_guard<std::mutex> lk(c.mu);
-    g_last_layer[c.device] = c.layer;
+    if (c.layer < MAX_LAYERS) g_last_layer[c.device] = c.layer;
     return (int)exgemm_dispatch(c, transa, transb, m, n, k, alpha, d_a, lda, d_b, ldb, beta, d_c, ldc, fpe,
                                 early_exit, round_mode(), st, chunks);
 }
@@ -573,6 +579,147 @@ int exb::exgemm_chunked_dev(char transa, char transb, int m, int n, int k, doubl
                      chunks);
 }
 extern "C" {
+
+// ---- context handles: independent accumulators, flags and workspace per caller-owned handle --------------------
+}  // extern "C"
+struct exblas_ctx {
+    exb::Ctx c;
+};
+// the handle's context; the calling thread must be on the handle's device (like any stream or buffer of that device)
+static Ctx *handle_ctx(exblas_ctx *h)
+{
+    if (!h) return &ctx(-1);
+    return current_device() == h->c.device ? &h->c : nullptr;
+}
+extern "C" {
+
+int exblas_ctx_create(exblas_ctx_t **out)
+{
+    if (!out) return (int)hipErrorInvalidValue;
+    ctx(-1);  // the device's default context first: a handle inherits the knobs set through the API
+    exblas_ctx *h = new exblas_ctx;
+    {
+        std::lock_guard<std::mutex> lk(g_ctx_mu);
+        init_ctx(h->c, current_device(), MAX_LAYERS);  // layer >= 1: inherits; >= MAX_LAYERS: not one of the static ones
+    }
+    *out = h;
+    return 0;
+}
+
+int exblas_ctx_destroy(exblas_ctx_t *h)
+{
+    if (!h) return 0;
+    Ctx &c = h->c;
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    hipError_t first = hipSetDevice(c.device);
+    hipError_t e = hipDeviceSynchronize();  // work enqueued on the handle may still be running
+    if (first == hipSuccess) first = e;
+    auto rel = [&](void *p) {
+        if (!p) return;
+        hipError_t e2 = hipFree(p);
+        if (first == hipSuccess) first = e2;
+    };
+    rel(c.gacc_all);
+    rel(c.gflags_all);
+    rel(c.d_record);
+    for (void *p : c.stage) rel(p);
+    for (void *p : c.retired) rel(p);
+    rel(c.ws);
+    if (c.h_record) (void)hipHostFree(c.h_record);
+    if (c.stream) (void)hipStreamDestroy(c.stream);
+    (void)hipSetDevice(prev);
+    delete h;
+    return (int)first;
+}
+
+#define EXB_HANDLE(h)              \
+    Ctx *cp = handle_ctx(h);       \
+    if (!cp) return (int)hipErrorInvalidDevice
+
+int exblas_exsum_accumulate_ctx(exblas_ctx_t *h, const double *d_a, int64_t n, int64_t inca, int fpe, int early_exit,
+                                void *stream)
+{
+    EXB_HANDLE(h);
+    return exsum_accumulate_on(*cp, d_a, n, inca, fpe, early_exit, (hipStream_t)stream);
+}
+
+int exblas_exdot_accumulate_ctx(exblas_ctx_t *h, const double *d_a, int64_t inca, const double *d_b, int64_t incb,
+                                int64_t n, int fpe, int early_exit, void *stream)
+{
+    EXB_HANDLE(h);
+    return exdot_accumulate_on(*cp, d_a, inca, d_b, incb, n, fpe, early_exit, (hipStream_t)stream);
+}
+
+int exblas_finish_ctx(exblas_ctx_t *h, void *stream, int64_t *d_out)
+{
+    EXB_HANDLE(h);
+    return finish_on(*cp, (hipStream_t)stream, d_out);
+}
+
+int exblas_exsum_ctx(exblas_ctx_t *h, const double *d_a, int64_t n, int64_t inca, int fpe, int early_exit, void *stream,
+                     int64_t *d_out)
+{
+    EXB_HANDLE(h);
+    int rc = exsum_accumulate_on(*cp, d_a, n, inca, fpe, early_exit, (hipStream_t)stream);
+    return rc ? rc : finish_on(*cp, (hipStream_t)stream, d_out);
+}
+
+int exblas_exdot_ctx(exblas_ctx_t *h, const double *d_a, int64_t inca, const double *d_b, int64_t incb, int64_t n, int fpe,
+                     int early_exit, void *stream, int64_t *d_out)
+{
+    EXB_HANDLE(h);
+    int rc = exdot_accumulate_on(*cp, d_a, inca, d_b, incb, n, fpe, early_exit, (hipStream_t)stream);
+    return rc ? rc : finish_on(*cp, (hipStream_t)stream, d_out);
+}
+
+int exblas_exgemv_ctx(exblas_ctx_t *h, char transa, int m, int n, double alpha, const double *d_a, int lda,
+                      const double *d_x, int incx, double beta, double *d_y, int incy, int fpe, int early_exit,
+                      void *stream)
+{
+    EXB_HANDLE(h);
+    return exgemv_on(*cp, transa, m, n, alpha, d_a, lda, d_x, incx, beta, d_y, incy, fpe, early_exit, (hipStream_t)stream);
+}
+
+int exblas_extrsv_ctx(exblas_ctx_t *h, char uplo, char transa, char diag, int n, const double *d_a, int lda, double *d_x,
+                      int incx, int fpe, int early_exit, void *stream)
+{
+    EXB_HANDLE(h);
+    return extrsv_on(*cp, uplo, transa, diag, n, d_a, lda, d_x, incx, fpe, early_exit, (hipStream_t)stream);
+}
+
+int exblas_exgemm_ctx(exblas_ctx_t *h, char transa, char transb, int m, int n, int k, double alpha, const double *d_a,
+                      int lda, const double *d_b, int ldb, double beta, double *d_c, int ldc, int fpe, int early_exit,
+                      void *stream)
+{
+    EXB_HANDLE(h);
+    return exgemm_on(*cp, transa, transb, m, n, k, alpha, d_a, lda, d_b, ldb, beta, d_c, ldc, fpe, early_exit,
+                     (hipStream_t)stream);
+}
+
+int exblas_reserve_workspace_ctx(exblas_ctx_t *h, size_t bytes)
+{
+    EXB_HANDLE(h);
+    std::lock_guard<std::mutex> lk(cp->mu);
+    hipError_t e = hipSuccess;
+    workspace(*cp, bytes, nullptr, &e);
+    return (int)e;
+}
+
+size_t exblas_workspace_bytes_ctx(exblas_ctx_t *h)
+{
+    Ctx *cp = handle_ctx(h);
+    if (!cp) return 0;
+    std::lock_guard<std::mutex> lk(cp->mu);
+    return cp->ws_bytes;
+}
+
+int exblas_last_gemm_info_ctx(exblas_ctx_t *h, int *out8)
+{
+    EXB_HANDLE(h);
+    return last_gemm_info_on(*cp, out8);
+}
+#undef EXB_HANDLE
 
 int exblas_reserve_workspace(size_t bytes)
 {

@@ -22,6 +22,25 @@ __device__ __forceinline__ d2_t ld2(const d2_t *p)
 // biased exponent field of a double, and the guard threshold 2^1000 (see fpe_absorb_sink)
 __device__ __forceinline__ unsigned expo_field(double x) { return ((unsigned)__double2hiint(x) >> 20) & 0x7ffu; }
 constexpr unsigned BIG_EXPO = 1023u + 1000u;
+// a product fl(a b) with an exponent field below this one (|a b| < 2^-968, zero included) may have bits below 2^-1074: its
+// TwoProd error term is then not representable
+constexpr unsigned LOW_EXPO = 1023u - 968u;
+
+// ExDOT: flag products of two non-zero operands whose low bits the accumulator cannot hold (FLAG_PUNDER, superacc.hip.h).
+// One exponent minimum + one wave-uniform vote per tile on the hot path; the per-element test (which needs the operands:
+// a product that underflowed to zero looks like 0 * x) only runs in tiles that hold a tiny or zero product.
+template <int CNT, class F>
+__device__ __forceinline__ void prod_underflow_note(const double (&p)[CNT], unsigned &flags, F &&both_nonzero)
+{
+    unsigned mn = 0x7ffu;
+#pragma unroll
+    for (int j = 0; j < CNT; ++j) mn = min(mn, expo_field(p[j]));
+    if (__any(mn < LOW_EXPO)) {
+#pragma unroll
+        for (int j = 0; j < CNT; ++j)
+            if (expo_field(p[j]) < LOW_EXPO && both_nonzero(j)) flags |= FLAG_PUNDER;
+    }
+}
 
 // "is any of these doubles non-zero" with 32-bit integer ops only (two per element instead of an fp64
 // compare each): OR of the low words and the high words shifted left by one (drops the sign, so -0.0 is zero)
@@ -48,11 +67,13 @@ struct LdsSink {
     long long *col;   // this lane's column of the wave's LDS accumulator, stride COPIES between limbs
     unsigned &flags;
     __device__ __forceinline__ void add(double x) { lds_add<COPIES>(col, x, flags); }
+    __device__ __forceinline__ void note(unsigned bits) { flags |= bits; }
 };
 
 // limbs of one accumulator in global memory: acc[0..NL) + three non-finite indicators at NL..NL+2
 struct GlobalSink {
     long long *acc;
+    __device__ __forceinline__ void note(unsigned) {}  // rows of a GEMV have no flag channel (y is plain doubles)
     __device__ __forceinline__ void add(double x)
     {
         const unsigned long long u = (unsigned long long)__double_as_longlong(x);
@@ -76,6 +97,20 @@ struct GlobalSink {
     }
 };
 
+// one product p + e = a * b straight into the integer accumulator.  The error term of a non-finite product is
+// meaningless (fma(a, b, -inf)) and is dropped; p = +-Inf with e = fma(a, b, -p) = -+Inf (not NaN) means both operands
+// were finite and the product overflowed: noted (FLAG_POVER).
+template <class Sink>
+__device__ __forceinline__ void sink_product(Sink &sink, double p, double e)
+{
+    sink.add(p);
+    if (expo_field(p) != 0x7ffu) {
+        if (e != 0.0) sink.add(e);
+    } else if (__builtin_isinf(p) && __builtin_isinf(e)) {
+        sink.note(FLAG_POVER);
+    }
+}
+
 // ---- the cascade -----------------------------------------------------------------------------
 // Range guard (one wave-uniform test per tile): TwoSum is only error-free while a + x stays finite.
 // When any lane of the wave holds an element of magnitude >= 2^1000 (or Inf/NaN), or an a[0] that has reached
@@ -97,8 +132,8 @@ __device__ __forceinline__ bool fpe_guard(double &a0, const double (&x)[CNT], co
     if (!__any(mx >= BIG_EXPO)) return false;
 #pragma unroll
     for (int j = 0; j < CNT; ++j) {
-        sink.add(x[j]);
-        if (e && e[j] != 0.0 && expo_field(x[j]) != 0x7ffu) sink.add(e[j]);
+        if (e) sink_product(sink, x[j], e[j]);
+        else sink.add(x[j]);
     }
     if (expo_field(a0) >= BIG_EXPO) {
         sink.add(a0);
@@ -193,8 +228,7 @@ __device__ __forceinline__ bool fpe_absorb_prod(double (&a)[N > 0 ? N : 1], doub
     if constexpr (N == 0) {
 #pragma unroll
         for (int j = 0; j < CNT; ++j) {
-            sink.add(p[j]);
-            if (e[j] != 0.0 && expo_field(p[j]) != 0x7ffu) sink.add(e[j]);
+            sink_product(sink, p[j], e[j]);
         }
         return false;
     } else {
@@ -218,8 +252,7 @@ __device__ __forceinline__ void fpe_absorb_prod_adaptive(double (&a)[N > 0 ? N :
             --bp.left;
 #pragma unroll
             for (int j = 0; j < CNT; ++j) {
-                sink.add(p[j]);
-                if (e[j] != 0.0 && expo_field(p[j]) != 0x7ffu) sink.add(e[j]);
+                sink_product(sink, p[j], e[j]);
             }
         } else if (fpe_absorb_prod<N, EE, CNT, Sink, ZM>(a, p, e, sink)) {
             bp.left = bp.span;

@@ -38,6 +38,13 @@ constexpr int SET_WORDS = 72;   // words [48,120) form one "digit set", summable
 constexpr int OUT_WORDS = 128;
 
 constexpr unsigned FLAG_PINF = 1u, FLAG_NINF = 2u, FLAG_NAN = 4u;
+// products (ExDOT): the double-range accumulator holds a 106-bit product only while it neither overflows nor reaches
+// below 2^-1074 -- the two limits the reference's kernels share (its MPFR test oracle uses 4196 bits for that reason,
+// tests/test.exdot.gpu.cpp:24-46).  They are fenced, not silent: PUNDER = some product of two non-zero operands is below
+// 2^-968 in magnitude, so bits of it below 2^-1074 were dropped (the result is then the correctly rounded sum of the
+// products truncated at 2^-1074); POVER = a product of two FINITE operands overflowed to +-Inf (the result is +-Inf / NaN
+// as in IEEE arithmetic although the exact sum may be finite).
+constexpr unsigned FLAG_PUNDER = 8u, FLAG_POVER = 16u, FLAG_NONFINITE = 7u;
 
 // ---------------------------------------------------------------------------------------------
 // error-free transforms (ExSUM.FPE.cl:27-32 KnuthTwoSum; ExDOT.Superacc.cl:25-29 TwoProductFMA)
@@ -247,7 +254,7 @@ __device__ inline void finish_record(long long *v, unsigned flags, long long *ou
     digits_to_canon(v, canon);
     unsigned long long ex = round_exact_bits(v);
     double rf = round_reference(canon);
-    if (flags) {
+    if (flags & FLAG_NONFINITE) {
         // IEEE semantics for non-finite inputs: NaN, or opposite infinities -> NaN; else +-inf
         const bool nan = (flags & FLAG_NAN) || ((flags & FLAG_PINF) && (flags & FLAG_NINF));
         ex = nan ? 0x7ff8000000000000ull
@@ -263,7 +270,7 @@ __device__ inline void finish_record(long long *v, unsigned flags, long long *ou
     out[OUT_FLAGCNT + 0] = (flags & FLAG_PINF) ? 1 : 0;
     out[OUT_FLAGCNT + 1] = (flags & FLAG_NINF) ? 1 : 0;
     out[OUT_FLAGCNT + 2] = (flags & FLAG_NAN) ? 1 : 0;
-    out[OUT_FLAGCNT + 3] = 0;
+    out[OUT_FLAGCNT + 3] = ((flags & FLAG_PUNDER) ? 1 : 0) + ((flags & FLAG_POVER) ? 65536 : 0);  // sums over ranks stay apart
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -465,7 +472,7 @@ __device__ inline WaveFinish finish_wave(long long v0, long long v1, const unsig
         }
     }
     }
-    if (flags) {
+    if (flags & FLAG_NONFINITE) {
         const bool nan = (flags & FLAG_NAN) || ((flags & FLAG_PINF) && (flags & FLAG_NINF));
         ex = nan ? 0x7ff8000000000000ull : ((flags & FLAG_NINF) ? 0xfff0000000000000ull : 0x7ff0000000000000ull);
         rf = __longlong_as_double((long long)ex);
@@ -487,7 +494,7 @@ __device__ inline void write_record_wave(const WaveFinish &r, unsigned flags, lo
         out[OUT_FLAGCNT + 0] = (flags & FLAG_PINF) ? 1 : 0;
         out[OUT_FLAGCNT + 1] = (flags & FLAG_NINF) ? 1 : 0;
         out[OUT_FLAGCNT + 2] = (flags & FLAG_NAN) ? 1 : 0;
-        out[OUT_FLAGCNT + 3] = 0;
+        out[OUT_FLAGCNT + 3] = ((flags & FLAG_PUNDER) ? 1 : 0) + ((flags & FLAG_POVER) ? 65536 : 0);  // sums over ranks stay apart
     }
     if (lane < CANON) out[OUT_CANON + lane] = r.canon;
     out[OUT_DIGITS + lane] = r.d0;

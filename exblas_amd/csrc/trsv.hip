@@ -53,6 +53,7 @@ struct RowSink {
         if (f) atomicOr(flagp, f);  // Inf / NaN: rare
         *touched = 1;
     }
+    __device__ __forceinline__ void note(unsigned) {}  // no flag channel per row of x
 };
 
 constexpr int DG_M = 3;    // expansion levels per row in the diagonal phase

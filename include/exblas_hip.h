@@ -24,6 +24,9 @@
  * The *_dev layer keeps ONE set of group accumulators and ONE workspace per device (two accumulator slots, see
  * exblas_set_accumulator_slot): its calls may come from any thread, but the work they enqueue must be ordered on
  * the device -- one stream, or streams chained by events -- exactly like kernels sharing a scratch buffer.
+ * Callers with several independent streams create one CONTEXT HANDLE per stream (exblas_ctx_create) and use the *_ctx
+ * entry points: every handle owns its accumulators, flags and workspace, so work enqueued through different handles
+ * may run concurrently in any order.
  * Workspace and hipGraphs: exgemv / exgemm / extrsv use a context workspace whose size depends on the problem.  It
  * only grows; a block it outgrows is parked (not freed) so that graphs captured earlier stay valid until
  * exblas_release_retired_workspaces().  Growth needs hipMalloc, which is illegal while a stream is being captured:
@@ -49,7 +52,14 @@ extern "C" {
 #define EXBLAS_OUT_WORDS 128
 #define EXBLAS_OUT_EXACT 0    /* bit pattern of the correctly rounded double */
 #define EXBLAS_OUT_REFMODE 1  /* bit pattern of the reference-compatible rounding */
-#define EXBLAS_OUT_FLAGS 2    /* bit0 +inf, bit1 -inf, bit2 NaN seen in the input */
+#define EXBLAS_OUT_FLAGS 2    /* bit0 +inf, bit1 -inf, bit2 NaN seen in the input; ExDOT also: bit3 = a product of two
+                               * non-zero operands was below 2^-968, so bits of it below 2^-1074 were dropped (the result is
+                               * the correctly rounded sum of the products truncated there); bit4 = a product of two FINITE
+                               * operands overflowed (the result is +-Inf / NaN as in IEEE arithmetic).  No bit set = the
+                               * result is the correctly rounded EXACT dot product (the MPFR-4196 value of
+                               * tests/test.exdot.gpu.cpp:24-46).  The reference's kernels have the same two limits, silently. */
+#define EXBLAS_FLAG_PRODUCT_UNDERFLOW 8
+#define EXBLAS_FLAG_PRODUCT_OVERFLOW 16
 #define EXBLAS_OUT_CANON 4    /* 41 canonical limbs (52-bit, reference geometry) */
 #define EXBLAS_OUT_DIGITS 48  /* 68 normalised 32-bit digits, then 3 flag indicators + 1 pad word: */
 #define EXBLAS_SET_WORDS 72   /* words [48,120) = one "digit set", the int64-sum all-reduce payload */
@@ -188,6 +198,40 @@ int exblas_stream_read_dev(const double *d_a, int64_t n, void *stream, double *d
 /* the same for the two-stream (ExDOT) access pattern: plain fp64 dot, blocks_per_cu <= 0 uses the ExDOT geometry */
 int exblas_stream_read2_dev(const double *d_a, const double *d_b, int64_t n, int blocks_per_cu, void *stream,
                             double *d_sink);
+
+/* ---- (2a) context handles ---------------------------------------------------------------------- */
+/* The reference launchers keep their kernels and buffers in file-static globals (src/gpu/blas/blas1/ExSUM.Launcher.cpp:
+ * 16-36): one call at a time per process.  The *_dev layer above relaxes that to "one ordered sequence per device"; a
+ * handle relaxes it completely: exblas_ctx_create (on the current device) allocates private group accumulators (both
+ * slots), flag words and -- on first use -- a private workspace; the *_ctx functions are the *_dev functions on that
+ * state (handle NULL = the device's default context = exactly the *_dev call).  Calls on ONE handle must still be
+ * ordered on the device; calls on different handles need no ordering at all.  A handle belongs to the device it was
+ * created on: using it while another device is current returns hipErrorInvalidDevice (101).  exblas_ctx_destroy
+ * synchronises the device and frees everything the handle owns (graphs captured through it must not be replayed
+ * afterwards).  Tuning knobs (exblas_set_tuning, exblas_set_gemm_path, ...) are inherited at creation. */
+typedef struct exblas_ctx exblas_ctx_t;
+int exblas_ctx_create(exblas_ctx_t **ctx);
+int exblas_ctx_destroy(exblas_ctx_t *ctx);
+int exblas_exsum_ctx(exblas_ctx_t *ctx, const double *d_a, int64_t n, int64_t inca, int fpe, int early_exit,
+                     void *stream, int64_t *d_out);
+int exblas_exdot_ctx(exblas_ctx_t *ctx, const double *d_a, int64_t inca, const double *d_b, int64_t incb, int64_t n,
+                     int fpe, int early_exit, void *stream, int64_t *d_out);
+int exblas_exsum_accumulate_ctx(exblas_ctx_t *ctx, const double *d_a, int64_t n, int64_t inca, int fpe, int early_exit,
+                                void *stream);
+int exblas_exdot_accumulate_ctx(exblas_ctx_t *ctx, const double *d_a, int64_t inca, const double *d_b, int64_t incb,
+                                int64_t n, int fpe, int early_exit, void *stream);
+int exblas_finish_ctx(exblas_ctx_t *ctx, void *stream, int64_t *d_out);
+int exblas_exgemv_ctx(exblas_ctx_t *ctx, char transa, int m, int n, double alpha, const double *d_a, int lda,
+                      const double *d_x, int incx, double beta, double *d_y, int incy, int fpe, int early_exit,
+                      void *stream);
+int exblas_extrsv_ctx(exblas_ctx_t *ctx, char uplo, char transa, char diag, int n, const double *d_a, int lda,
+                      double *d_x, int incx, int fpe, int early_exit, void *stream);
+int exblas_exgemm_ctx(exblas_ctx_t *ctx, char transa, char transb, int m, int n, int k, double alpha,
+                      const double *d_a, int lda, const double *d_b, int ldb, double beta, double *d_c, int ldc,
+                      int fpe, int early_exit, void *stream);
+int exblas_reserve_workspace_ctx(exblas_ctx_t *ctx, size_t bytes);
+size_t exblas_workspace_bytes_ctx(exblas_ctx_t *ctx);
+int exblas_last_gemm_info_ctx(exblas_ctx_t *ctx, int *out8);
 
 /* ---- (2b) multi-GPU: one process per GPU ----------------------------------------------------- */
 /* The reference reduces across processes inside the library call: local reduction, MPI_Reduce(MPI_LONG, MPI_SUM) of

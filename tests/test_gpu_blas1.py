@@ -385,3 +385,94 @@ def test_blas1_randomized_soak(ex):
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_blas1.py"), "150", "5"],
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "0 mismatches" in r.stdout, (r.stdout[-3000:], r.stderr[-2000:])
+
+
+FLAG_PUNDER, FLAG_POVER = 8, 16
+
+
+def test_exdot_product_domain_is_fenced(ex, oracle):
+    """The double-range accumulator holds a 106-bit product only while it neither overflows nor reaches below 2^-1074 --
+    the limit the reference's kernels share (its test oracle sums exact products in 4196 bits for that reason,
+    tests/test.exdot.gpu.cpp:24-46).  Outside that domain the record says so (EXBLAS_OUT_FLAGS bit 3 / bit 4); inside it
+    -- no flag -- the result IS the MPFR-4196 value.  Families: products straddling 2^-968 (the first exponent whose
+    TwoProd error term can fall below 2^-1074), products that underflow to zero, finite operands whose product
+    overflows, and zeros (0 * x must not raise the flag).  Every variant, vector / strided / odd-tail code paths."""
+    import torch
+    rng = np.random.default_rng(11)
+    mp = oracle.mpfr()
+
+    def run(a, b, fpe, ee, inca=1):
+        rec = ex.read_record(ex.exdot_dev(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), fpe, ee, incx=inca,
+                                          incy=inca, n=(a.size + inca - 1) // inca))
+        # the oracle restates the same arithmetic (fma error terms rounded where they underflow): limbs stay equal
+        r, limbs = oracle.exdot(a, b, fpe, ee, inca=inca, incb=inca, limbs=True)
+        assert (rec.canon == limbs).all() and same_double(rec.exact, r)
+        return rec
+
+    n = 20000 + 3                                     # odd: the scalar tail runs too
+    mant = lambda k: rng.uniform(1.0, 2.0, k) * rng.choice([-1.0, 1.0], k)  # noqa: E731
+    big = np.ldexp(mant(n), rng.integers(-20, 20, n))
+    for fpe, ee in FPE_VARIANTS_DOT:
+        # (1) safely inside: every product at or above 2^-960 -> no flag, equal to MPFR-4196
+        a = np.ldexp(mant(n), rng.integers(-480, -450, n))
+        b = np.ldexp(mant(n), rng.integers(-480, -440, n))
+        rec = run(a, b, fpe, ee)
+        assert rec.flags == 0
+        if mp is not None:
+            assert same_double(rec.exact, oracle.mpfr_exdot(a, b)), (fpe, ee)
+        # (2) ONE product below 2^-968 among ordinary ones -> bit 3, result finite
+        a2, b2 = big.copy(), big[::-1].copy()
+        j = int(rng.integers(0, n))
+        a2[j], b2[j] = np.ldexp(1.5, -500), np.ldexp(1.25, -480)          # 2^-980: error term below 2^-1074
+        rec = run(a2, b2, fpe, ee)
+        assert rec.flags == FLAG_PUNDER and np.isfinite(rec.exact), (fpe, ee, rec.flags)
+        # (3) a product that underflows to zero entirely
+        a2[j], b2[j] = np.ldexp(1.0, -600), np.ldexp(1.0, -600)
+        assert run(a2, b2, fpe, ee).flags == FLAG_PUNDER
+        # (4) zeros are not underflow: 0 * x, x * 0, 0 * 0, subnormal * 0
+        a3, b3 = big.copy(), big[::-1].copy()
+        a3[::7] = 0.0
+        b3[::5] = 0.0
+        a3[3], b3[3] = 5e-324, 0.0
+        rec = run(a3, b3, fpe, ee)
+        assert rec.flags == 0
+        if mp is not None:
+            assert same_double(rec.exact, oracle.mpfr_exdot(a3, b3)), (fpe, ee)
+        # (5) finite operands, overflowing product -> bit 4 and +Inf / -Inf / NaN as IEEE arithmetic gives
+        a4, b4 = big.copy(), big[::-1].copy()
+        a4[j], b4[j] = np.ldexp(1.0, 600), np.ldexp(1.0, 500)
+        rec = ex.read_record(ex.exdot_dev(torch.from_numpy(a4).cuda(), torch.from_numpy(b4).cuda(), fpe, ee))
+        assert rec.flags == (FLAG_POVER | 1) and rec.exact == np.inf, (fpe, ee, rec.flags, rec.exact)
+        a4[j] = -a4[j]
+        rec = ex.read_record(ex.exdot_dev(torch.from_numpy(a4).cuda(), torch.from_numpy(b4).cuda(), fpe, ee))
+        assert rec.flags == (FLAG_POVER | 2) and rec.exact == -np.inf
+        # a true Inf operand is NOT a product overflow
+        a4[j], b4[j] = np.inf, 2.0
+        rec = ex.read_record(ex.exdot_dev(torch.from_numpy(a4).cuda(), torch.from_numpy(b4).cuda(), fpe, ee))
+        assert rec.flags == 1 and rec.exact == np.inf
+    # strided path and the exact boundary: 2^-968 itself is inside (error term >= 2^-1074 representable)
+    a = np.zeros(64)
+    b = np.zeros(64)
+    a[0], b[0] = np.ldexp(1.0 + 2.0 ** -52, -484), np.ldexp(1.0 + 2.0 ** -52, -484)   # product 2^-968 (1 + 2^-51 + 2^-104)
+    a[2], b[2] = 3.0, 5.0
+    rec = run(a, b, 8, True, inca=2)
+    assert rec.flags == 0
+    if mp is not None:
+        assert same_double(rec.exact, oracle.mpfr_exdot(a, b, inca=2, incb=2, n=32))
+    a[0] = np.ldexp(1.0 + 2.0 ** -52, -485)                                            # one binade lower: flagged
+    assert run(a, b, 8, True, inca=2).flags == FLAG_PUNDER
+
+
+def test_exdot_flags_survive_the_digit_set(ex):
+    """The product flags travel with the 576-byte digit set (its pad word), so an all-reduced result carries the OR over
+    the ranks: finalize over the digit sets of two records, one flagged, is flagged."""
+    import torch
+    a = torch.tensor([2.0 ** -500, 1.0], dtype=torch.float64, device="cuda")
+    b = torch.tensor([2.0 ** -490, 3.0], dtype=torch.float64, device="cuda")
+    r1 = ex.exdot_dev(a, b, 8, True)
+    r2 = ex.exdot_dev(b[1:], b[1:], 8, True)
+    assert ex.read_record(r1).flags == FLAG_PUNDER and ex.read_record(r2).flags == 0
+    sets = torch.stack([r1[ex.OUT_DIGITS:ex.OUT_DIGITS + ex.SET_WORDS], r2[ex.OUT_DIGITS:ex.OUT_DIGITS + ex.SET_WORDS]])
+    tot = ex.read_record(ex.finalize_dev(sets.contiguous()))
+    assert tot.flags == FLAG_PUNDER
+    assert tot.exact == 2.0 ** -990 + 3.0 + 9.0
