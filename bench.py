@@ -498,6 +498,23 @@ def launch_ranks(args):
     sys.exit(0)
 
 
+class stdout_to_stderr:
+    """fd-level redirection: RCCL prints a version banner on stdout when its first communicator comes up (torch's and
+    ours); the contract is ONE JSON line on stdout"""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def record_ids(rec):
     """the 8 bytes of the rounded result (both roundings) and a CRC of the 41 canonical limbs: equal across GPU counts"""
     import struct
@@ -555,49 +572,55 @@ def main():
     comm = None
     transport = "none (single GPU)"
     force_dist = os.environ.get("EXBLAS_BENCH_FORCE_DIST") == "1"  # rehearse the RCCL path with a 1-rank communicator
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # torch.distributed is the CONTROL plane only (barriers, the max-over-ranks of the timings, handing out the
-        # RCCL unique id); the data-path collectives are issued by libexblas.so on its own RCCL communicator.
-        # EXBLAS_BENCH_BACKEND=gloo rehearses the N > 1 control flow on a box with fewer GPUs than ranks (ranks then
-        # share the devices round-robin and the library uses its host-callback transport).
-        backend = os.environ.get("EXBLAS_BENCH_BACKEND", "nccl")
-        if backend == "nccl":
-            if torch.cuda.device_count() < world:
-                print(f"[bench] rank {rank}: {world} ranks but {torch.cuda.device_count()} devices", file=sys.stderr,
-                      flush=True)
-                sys.exit(2)
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-            transport = "native RCCL int64 all-reduce (ncclAllReduce issued by libexblas.so)"
+    with stdout_to_stderr():
+        if world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            # torch.distributed is the CONTROL plane only (barriers, the max-over-ranks of the timings, handing out the
+            # RCCL unique id); the data-path collectives are issued by libexblas.so on its own RCCL communicator.
+            # EXBLAS_BENCH_BACKEND=gloo rehearses the N > 1 control flow on a box with fewer GPUs than ranks (ranks then
+            # share the devices round-robin and the library uses its host-callback transport).
+            backend = os.environ.get("EXBLAS_BENCH_BACKEND", "nccl")
+            if backend == "nccl":
+                if torch.cuda.device_count() < world:
+                    print(f"[bench] rank {rank}: {world} ranks but {torch.cuda.device_count()} devices", file=sys.stderr,
+                          flush=True)
+                    sys.exit(2)
+                torch.cuda.set_device(local_rank)
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+                transport = "native RCCL int64 all-reduce (ncclAllReduce issued by libexblas.so)"
+            else:
+                torch.cuda.set_device(local_rank % torch.cuda.device_count())
+                dist.init_process_group(backend)
+            try:
+                comm = ex.Comm.from_torch()
+            except Exception as e:  # noqa: BLE001
+                print(f"[bench] rank {rank}: native communicator could not be created: {e}", file=sys.stderr, flush=True)
+            if backend == "nccl":
+                # every rank must take the same branch: if the RCCL communicator inside libexblas.so failed anywhere, all
+                # ranks fall back to the library's host-callback transport over a gloo group (slower, same bits) and the
+                # JSON line says so -- a number with a caveat beats no number
+                okt = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device="cuda")
+                dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+                if int(okt.item()) == 0:
+                    if comm is not None:
+                        comm.destroy()
+                    comm = ex.Comm.from_torch(dist.new_group(backend="gloo"), transport="host")
+                    transport = "host-callback transport over a gloo group (the native RCCL communicator could not be created)"
+            elif comm is None:
+                raise SystemExit("no communicator")
+            else:
+                transport = "host-callback transport (gloo rehearsal, ranks may share a GPU)"
         else:
-            torch.cuda.set_device(local_rank % torch.cuda.device_count())
-            dist.init_process_group(backend)
-        try:
-            comm = ex.Comm.from_torch()
-        except Exception as e:  # noqa: BLE001
-            print(f"[bench] rank {rank}: native communicator could not be created: {e}", file=sys.stderr, flush=True)
-        if backend == "nccl":
-            # every rank must take the same branch: if the RCCL communicator inside libexblas.so failed anywhere, all
-            # ranks fall back to the library's host-callback transport over a gloo group (slower, same bits) and the
-            # JSON line says so -- a number with a caveat beats no number
-            okt = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device="cuda")
-            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
-            if int(okt.item()) == 0:
-                if comm is not None:
-                    comm.destroy()
-                comm = ex.Comm.from_torch(dist.new_group(backend="gloo"), transport="host")
-                transport = "host-callback transport over a gloo group (the native RCCL communicator could not be created)"
-        elif comm is None:
-            raise SystemExit("no communicator")
-        else:
-            transport = "host-callback transport (gloo rehearsal, ranks may share a GPU)"
-    else:
-        torch.cuda.set_device(0)
-        if force_dist:
-            comm = ex.Comm.rccl(ex.Comm.unique_id(), 0, 1)
-            transport = "native RCCL, one-rank communicator (rehearsal)"
+            torch.cuda.set_device(0)
+            if force_dist:
+                comm = ex.Comm.rccl(ex.Comm.unique_id(), 0, 1)
+                transport = "native RCCL, one-rank communicator (rehearsal)"
+        if comm is not None:
+            # the first collective brings the transports up (and RCCL's banner out) while stdout is still redirected
+            ex.read_record(ex.exsum_allreduce(comm, torch.zeros(2, dtype=torch.float64, device="cuda"), 8, True))
+            if dist is not None:
+                dist.barrier()
     lib = ex.load_library()
     lib.exblas_hip_init(-1)
     n_ranks_seen = lib.exblas_comm_size(comm.handle) if comm is not None else 1

@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <atomic>
 #include <thread>
 #include <vector>
 
@@ -38,6 +39,8 @@ static int env_int(const char *name, int dflt)
     const char *s = getenv(name);
     return (s && *s) ? atoi(s) : dflt;
 }
+
+std::atomic<bool> g_comm_created{false};  // set by comm.hip when a communicator of more than one rank is created
 
 static int g_round_mode = -1;
 int round_mode()
@@ -871,9 +874,19 @@ static std::vector<int> host_devices(long long bytes)
     std::vector<int> devs = g_host_devs;
     if (devs.empty()) {
         // default: one big call uses every GPU this process can see (8 PCIe links instead of 1); small ones do not
-        // pay for waking the other devices
+        // pay for waking the other devices.  NOT in a one-process-per-GPU job (a launcher's rank variables in the
+        // environment, or a communicator created through exblas_comm_*): every rank sees all devices there, and a rank
+        // that spread its host calls would create contexts and push PCIe traffic on its peers' GPUs -- the reference's
+        // GPU backend uses exactly one device per call (gpu:ExSUM.cpp:86-126).
+        static const bool rank_env = [] {
+            for (const char *v : {"WORLD_SIZE", "OMPI_COMM_WORLD_SIZE", "PMI_SIZE", "SLURM_NTASKS"}) {
+                const char *e = getenv(v);
+                if (e && atoi(e) > 1) return true;
+            }
+            return false;
+        }();
         const int ndev = exblas_hip_device_count();
-        if (bytes >= HOST_SPLIT_MIN_BYTES && ndev > 1)
+        if (bytes >= HOST_SPLIT_MIN_BYTES && ndev > 1 && !rank_env && !exb::g_comm_created.load())
             for (int d = 0; d < ndev && d < MAX_LAYERS - 1; ++d) devs.push_back(d);
         else
             devs.push_back(-1);

@@ -27,9 +27,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <vector>
 
 namespace exb {
+
+extern std::atomic<bool> g_comm_created;  // capi.hip: a process that owns a communicator is one rank of a multi-GPU job
 
 struct RcclApi {
     void *handle = nullptr;
@@ -265,6 +268,7 @@ int exblas_comm_init_rccl(exblas_comm_t **comm, int nranks, int rank, const void
     cm->owned = true;
     (void)hipGetDevice(&cm->device);
     *comm = cm;
+    if (nranks > 1) g_comm_created.store(true);
     return 0;
 }
 
@@ -282,6 +286,7 @@ int exblas_comm_adopt_rccl(exblas_comm_t **comm, void *nccl_comm, int nranks, in
     cm->owned = false;
     (void)hipGetDevice(&cm->device);
     *comm = cm;
+    if (nranks > 1) g_comm_created.store(true);
     return 0;
 }
 
@@ -299,6 +304,7 @@ int exblas_comm_init_host(exblas_comm_t **comm, int nranks, int rank, exblas_hos
     cm->h_allgatherv = allgatherv;
     cm->user = user;
     *comm = cm;
+    if (nranks > 1) g_comm_created.store(true);
     return 0;
 }
 

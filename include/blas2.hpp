@@ -16,7 +16,10 @@ int extrsv(const char uplo, const char transa, const char diag, const int n, dou
            const bool early_exit = false);
 
 /**
- * y := round(alpha * op(A) * x (+) beta * y), every y_i the correctly rounded exact row sum.
+ * y_i := Round(sum_k op(A)_ik * fl(alpha * x_k)  (+)  beta * y_i): the sum -- including beta * y_i, exactly (beta = 1: y_i
+ * itself; otherwise the error-free product) -- is exact and rounded once, correctly.  alpha is folded into x by a
+ * ROUNDED multiply per element first, as the reference's kernel does (ExGEMV.Superacc.cl:238): for alpha other than
+ * 0, +-1 or a power of two the result is the correctly rounded product with the rounded vector, not with alpha * x.
  * A is column-major with leading dimension lda.  fpe == 0 superaccumulators only, fpe == 1 plain
  * (non-reproducible) DGEMV, otherwise floating-point expansions as in exsum.
  */

@@ -307,7 +307,10 @@ int exblas_exgemm_sharded_dev(exblas_comm_t *comm, char transa, char transb, int
 /* exsum / exdot of host vectors spread one call over several GPUs of the node (each streams its contiguous part in
  * 64 MiB chunks through its own PCIe link; the 576-byte digit sets of the parts are added and rounded once): the
  * reference's rank-0 scatter (cpu:ExSUM.cpp:33-63) inside one process.  Default: every visible device for inputs of
- * 256 MiB or more, the current device otherwise; `EXBLAS_HOST_DEVICES=all|current|0,1,...` or this call override it
+ * 256 MiB or more in a stand-alone process; always the current device only in a one-process-per-GPU job (a launcher's
+ * WORLD_SIZE / OMPI_COMM_WORLD_SIZE / PMI_SIZE / SLURM_NTASKS > 1 in the environment, or a communicator of
+ * more than one rank created through exblas_comm_*), where every rank sees its peers' devices;
+ * `EXBLAS_HOST_DEVICES=all|current|0,1,...` or this call override it
  * (count == 0 restores the default; a device may be listed twice -- two independent parts on one GPU).  The result
  * does not depend on the choice.  exgemv / exgemm / extrsv always use the current device. */
 int exblas_set_host_devices(int count, const int *devices);
