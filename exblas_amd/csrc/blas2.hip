@@ -371,7 +371,6 @@ __global__ void __launch_bounds__(GV_BLOCK, MINW) k_gemvT(int m, const double *_
 
     const bool vec = ((((uintptr_t)col) | ((uintptr_t)x)) & 15u) == 0;
     long long done = 0;
-    Bypass bypass;
     if (vec) {
         const d2_t *va = (const d2_t *)col, *vx = (const d2_t *)x;
         const long long nv = m >> 1, tile = (long long)GV_BLOCK * U, ntiles = nv / tile;
@@ -396,6 +395,7 @@ __global__ void __launch_bounds__(GV_BLOCK, MINW) k_gemvT(int m, const double *_
                     qx[u] = vx[base + u * 64];  // x is re-read by every workgroup: keep it cacheable
                 }
             };
+            // returns (wave-uniform) whether the tile spilled: the data's exponent range outgrows the expansion
             auto absorb = [&](d2_t (&qa)[U], d2_t (&qx)[U]) {
                 double p[2 * U], e[2 * U];
 #pragma unroll
@@ -403,16 +403,34 @@ __global__ void __launch_bounds__(GV_BLOCK, MINW) k_gemvT(int m, const double *_
                     p[2 * u] = two_prod(qa[u].x, qx[u].x, e[2 * u]);
                     p[2 * u + 1] = two_prod(qa[u].y, qx[u].y, e[2 * u + 1]);
                 }
-                fpe_absorb_prod_adaptive<N, EE, 2 * U, LdsSink<COPIES>, ZM>(f, p, e, sink, bypass);
+                return fpe_absorb_prod<N, EE, 2 * U, LdsSink<COPIES>, ZM>(f, p, e, sink);
             };
+            // After a spill the REST OF THE COLUMN goes straight to the integer accumulator in a loop of its own (a
+            // column is 16 tiles per lane at m = 32768: shorter than the shortest bypass span of fpe_absorb_prod_adaptive,
+            // which this replaces here).  Keeping the bypass as a per-tile flag inside the one loop cost the hot path 7
+            // v_mov_b64 (the expansion's registers merged after the branch) and 8 hoisted v_bfe per tile.
+            long long tt = 0;
+            bool direct = false;
             fill(0, ra, rx);
-            for (long long tt = 0;;) {
+            for (;;) {
                 fill(tt + 1, rb, ry);
-                absorb(ra, rx);
-                if (++tt >= ntiles) break;
+                direct = absorb(ra, rx);
+                if (++tt >= ntiles || direct) break;
                 fill(tt + 1, ra, rx);
-                absorb(rb, ry);
-                if (++tt >= ntiles) break;
+                direct = absorb(rb, ry);
+                if (++tt >= ntiles || direct) break;
+            }
+            if (N > 0 && direct) {
+                for (; tt < ntiles; ++tt) {
+                    fill(tt, ra, rx);
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        double e0, e1;
+                        const double p0 = two_prod(ra[u].x, rx[u].x, e0), p1 = two_prod(ra[u].y, rx[u].y, e1);
+                        sink_product(sink, p0, e0);
+                        sink_product(sink, p1, e1);
+                    }
+                }
             }
         }
         done = ntiles * tile * 2;

@@ -35,7 +35,7 @@ __device__ __forceinline__ void prod_underflow_note(const double (&p)[CNT], unsi
     unsigned mn = 0x7ffu;
 #pragma unroll
     for (int j = 0; j < CNT; ++j) mn = min(mn, expo_field(p[j]));
-    if (__any(mn < LOW_EXPO)) {
+    if (__builtin_expect(__any(mn < LOW_EXPO), 0)) {
 #pragma unroll
         for (int j = 0; j < CNT; ++j)
             if (expo_field(p[j]) < LOW_EXPO && both_nonzero(j)) flags |= FLAG_PUNDER;
@@ -129,7 +129,7 @@ __device__ __forceinline__ bool fpe_guard(double &a0, const double (&x)[CNT], co
     unsigned mx = expo_field(a0);
 #pragma unroll
     for (int j = 0; j < CNT; ++j) mx = max(mx, expo_field(x[j]));
-    if (!__any(mx >= BIG_EXPO)) return false;
+    if (__builtin_expect(!__any(mx >= BIG_EXPO), 1)) return false;
 #pragma unroll
     for (int j = 0; j < CNT; ++j) {
         if (e) sink_product(sink, x[j], e[j]);
@@ -206,7 +206,7 @@ __device__ __forceinline__ void fpe_absorb_adaptive(double (&a)[N > 0 ? N : 1], 
     if constexpr (N == 0) {
         fpe_absorb_sink<N, EE, CNT, Sink, ZM>(a, x, 0, sink);
     } else {
-        if (bp.left > 0) {  // wave-uniform
+        if (__builtin_expect(bp.left > 0, 0)) {  // wave-uniform
             --bp.left;
 #pragma unroll
             for (int j = 0; j < CNT; ++j) sink.add(x[j]);
@@ -248,7 +248,7 @@ __device__ __forceinline__ void fpe_absorb_prod_adaptive(double (&a)[N > 0 ? N :
     if constexpr (N == 0) {
         fpe_absorb_prod<N, EE, CNT>(a, p, e, sink);
     } else {
-        if (bp.left > 0) {
+        if (__builtin_expect(bp.left > 0, 0)) {
             --bp.left;
 #pragma unroll
             for (int j = 0; j < CNT; ++j) {

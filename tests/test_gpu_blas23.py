@@ -41,6 +41,30 @@ def test_exgemv_vs_oracle(ex, oracle, trans, m, n):
             assert (_bits(y) == _bits(want)).all(), (trans, m, n, kind, fpe, ee, np.nonzero(y != want)[0][:5])
 
 
+@pytest.mark.parametrize("trans", ["N", "T"])
+def test_exgemv_long_vectors_wide_range(ex, oracle, trans):
+    """Columns / rows long enough for the tiled vector loops (m >= 2048 for 'T': several 2048-element tiles + a ragged
+    tail; n >= 16 column groups drawn dynamically for 'N') on data whose exponent range outgrows the small expansions:
+    tiles spill, 'T' sends the rest of the column through its direct loop (straight to the integer accumulator), the
+    range guard diverts whole tiles (|x| >= 2^1000 entries).  Every variant, the oracle's bits."""
+    m, n = (3 * 2048 + 77, 40) if trans == "T" else (520, 3 * 128 + 5)
+    lda = m + 2
+    rows, inner = (n, m) if trans == "T" else (m, n)
+    for kind, p0, p1 in (("fpuniform_signed", 600, 300), ("lognormal", 0.0, 50.0), ("fpuniform", 10, 0)):
+        a = oracle.gen(kind, lda * n, 151, p0, p1)
+        x = oracle.gen("fpuniform_signed", inner, 152, 20, 10)
+        y0 = oracle.gen("fpuniform_signed", rows, 153, 20, 10)
+        if kind == "fpuniform":                       # a few entries the guard must divert (products stay finite)
+            a[5 * lda + 7] = 2.0 ** 1010
+            a[9 * lda + (m - 3)] = -(2.0 ** 1005)
+            x[:] = np.where(np.abs(x) > 1.0, 1.0, x)
+        want = oracle.exgemv(trans, m, n, 1.0, a, lda, x, 1.0, y0, 0)
+        for fpe, ee in GEMV_VARIANTS:
+            y = y0.copy()
+            ex.exgemv(trans, m, n, 1.0, a, lda, 0, x, 1, 0, 1.0, y, 1, 0, fpe, ee)
+            assert (_bits(y) == _bits(want)).all(), (trans, kind, fpe, ee, np.nonzero(y != want)[0][:5])
+
+
 def test_exgemv_alpha_beta_strides_offsets(ex, oracle):
     m, n, lda = 300, 210, 301
     a = oracle.gen("fpuniform_signed", lda * n + 5, 61, 40, 20)
