@@ -32,6 +32,7 @@ namespace exb {
 constexpr int CRT_LMAX = 39;      // moduli available: 285 bits (126 + 126 bits of operands and k up to 2^31)
 constexpr int CRT_G = 13;         // groups of three moduli
 constexpr int CRT_W32 = 10;       // 32-bit words of the reconstructed integer (320 bits)
+constexpr int CRT_NL24 = 12;      // 24-bit limbs (carried in doubles) that hold M_L for L <= 39 (288 >= 285 bits)
 constexpr int CRT_BT = 256;       // block of C per workgroup: 256 x 256
 constexpr int CRT_KPASS = 128;    // k chunks (of 64) per launch: 8192 * 2^14 = 2^27 < 2^31
 
@@ -41,13 +42,14 @@ struct CrtTables {
     unsigned c8[CRT_LMAX][4];        // 256^t mod p for t = 0..15, byte t%4 of word t/4
     int bits[CRT_LMAX + 1];          // floor(log2(M_L)), M_L = p_0 ... p_{L-1}
     double P[CRT_G][3], invP[CRT_G][3];             // super-modulus of group b when it holds w + 1 moduli
+    double invPlow[CRT_G][3];                       // a shade below 1/P: floor(x invPlow) is floor(x / P) or one less
     // with L moduli in use (the last group then holds L - 3 (G - 1) of its three):
     double wc[CRT_LMAX + 1][CRT_G];                 // (M_L / P_b)^-1 mod P_b
     // gc[L][b][j] = wc[L][b] * e_j mod P_b, e_j the CRT basis of modulus j inside group b (1 mod p_j, 0 mod the others;
     // 0 for a modulus the last group does not use):  y_b = (sum_j r_j gc[L][b][j]) mod P_b  in one reduction
     double gc[CRT_LMAX + 1][CRT_G][3];
-    unsigned MP[CRT_LMAX + 1][CRT_G][CRT_W32];      // M_L / P_b
-    unsigned M[CRT_LMAX + 1][CRT_W32];              // M_L
+    double ml[CRT_LMAX + 1][CRT_G][CRT_NL24];       // M_L / P_b in 24-bit limbs, least significant first
+    double Ml[CRT_LMAX + 1][CRT_NL24];              // M_L in 24-bit limbs
 };
 
 __device__ CrtTables g_crt;
@@ -97,6 +99,13 @@ struct Big {  // little-endian 32-bit words
         for (int i = CRT_W32 + 1; i >= 0; --i) rem = ((rem << 32) | w[i]) % d;
         return (uint32_t)rem;
     }
+    double limb24(int i) const  // bits [24 i, 24 i + 24)
+    {
+        const int bit = 24 * i, wi = bit >> 5, sh = bit & 31;
+        uint64_t v = wi < CRT_W32 + 2 ? w[wi] : 0u;
+        if (wi + 1 < CRT_W32 + 2) v |= (uint64_t)w[wi + 1] << 32;
+        return (double)((v >> sh) & 0xffffffu);
+    }
     int bitlen() const
     {
         for (int i = CRT_W32 + 1; i >= 0; --i)
@@ -133,6 +142,7 @@ const CrtTables &crt_tables_host()
             for (int w = 0; w < 3; ++w) {
                 t.P[b][w] = (double)Pw[w];
                 t.invP[b][w] = 1.0 / (double)Pw[w];
+                t.invPlow[b][w] = (1.0 / (double)Pw[w]) * (1.0 - 1.0 / (double)(1ll << 30));
             }
         }
         Big mm;
@@ -140,14 +150,14 @@ const CrtTables &crt_tables_host()
         for (int l = 0; l <= CRT_LMAX; ++l) {
             if (l > 0) mm.mul_small((uint32_t)t.p[l - 1]);
             t.bits[l] = mm.bitlen() - 1;
-            for (int i = 0; i < CRT_W32; ++i) t.M[l][i] = mm.w[i];
+            for (int i = 0; i < CRT_NL24; ++i) t.Ml[l][i] = mm.limb24(i);
             const int G = (l + 2) / 3;
             for (int b = 0; b < G; ++b) {
                 const int w = b == G - 1 ? l - 3 * (G - 1) : 3;
                 const uint32_t Pb = (uint32_t)t.P[b][w - 1];
                 Big q = mm;
                 q.div_small(Pb);  // exact
-                for (int i = 0; i < CRT_W32; ++i) t.MP[l][b][i] = q.w[i];
+                for (int i = 0; i < CRT_NL24; ++i) t.ml[l][b][i] = q.limb24(i);
                 const long long wcl = inv_mod((long long)q.mod_small(Pb), (long long)Pb);
                 t.wc[l][b] = (double)wcl;
                 for (int j = 0; j < 3; ++j) {
@@ -165,24 +175,131 @@ const CrtTables &crt_tables_host()
 
 }  // namespace
 
-__host__ __device__ __forceinline__ double crt_dmod(double z, double P, double invP)  // z mod P for |z| < 2^50, P < 2^24
+// ---------------------------------------------------------------------------------------------
+// reconstruction core, shared by the kernel and by the host self-test (same code, same tables)
+// ---------------------------------------------------------------------------------------------
+// Moduli in groups of three with the 24-bit super-modulus P_b; the classical CRT formula on two levels:
+//   value = sum_b y_b (M / P_b) - kappa M,   y_b = (sum_j r_j gc_j) mod P_b  (gc_j folds the basis inside the group and the
+//   group's weight (M / P_b)^-1 mod P_b; the sum is an exact integer below 2^34),   kappa = round(sum_b y_b / P_b).
+// y_b is left NON-canonical in [0, 2 P_b) (one multiply, one floor, one fma; no fix-ups): an extra P_b adds exactly M to
+// the sum and exactly 1 to the fraction sum, so kappa absorbs it.  kappa is exact because |value| / M < 1/4 (k_crt_decide)
+// while the fraction sum is good to 1e-14.  The big products live in 24-bit limbs carried in doubles -- y_b < 2^25 times a
+// limb < 2^24, at most 13 groups: every limb sum is an exact integer below 2^53 -- i.e. NL fused multiply-adds per group
+// where 32-bit words took a v_mad_u64_u32 carry chain (~3 instructions per word), and no carries until the end.
+template <int NL>
+struct CrtAcc {
+    double limb[NL];
+    double phi;
+};
+
+template <int NL>
+__host__ __device__ __forceinline__ void crt_acc_zero(CrtAcc<NL> &a)
 {
-    const double q = floor(z * invP);
-    double r = fma(-q, P, z);  // exact; q is off by at most one
-    r = r < 0.0 ? r + P : r;
-    r = r >= P ? r - P : r;
-    return r;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) a.limb[i] = 0.0;
+    a.phi = 0.0;
 }
 
-// Thread = (group of 4 rows, column): the L words R[t][g][j] hold the residues of its 4 entries, loaded two groups of
-// moduli ahead of their use.  Moduli in groups of three with the 24-bit super-modulus P_b; the classical formula on two
-// levels:  value = sum_b y_b (M / P_b) - kappa M,  y_b = x_b (M / P_b)^-1 mod P_b = (sum_j r_j gc_j) mod P_b (x_b the
-// residue modulo P_b, never formed):  the big products in 32-bit words, kappa = round(sum_b y_b / P_b) in fp64 -- exact
-// because |value| / M < 1/4 (k_crt_decide) while the fraction sum is good to 1e-14.  The table entries of a group are wave-uniform scalars, read
-// once for the four entries.
-// Host mirror of k_crt_finish's arithmetic over the same tables (CPU-only check of the table generator and of the
-// reconstruction formulas, tests/test_abi.py): random integers |S| < M_L / 4 for every L -> residues -> groups ->
-// classical CRT sum -> minus kappa M_L; the 320-bit two's-complement result must be S again.
+// one group: residues r0, r1, r2 (a modulus the last group does not use: any value, its coefficient is zero)
+template <int NL>
+__host__ __device__ __forceinline__ void crt_group_step(CrtAcc<NL> &a, double r0, double r1, double r2, double c0, double c1,
+                                                        double c2, double P, double invP, double invPlow, const double (&ml)[NL])
+{
+    const double x = fma(r2, c2, fma(r1, c1, r0 * c0));   // exact, < 2^34
+    const double y = fma(-floor(x * invPlow), P, x);       // x mod P, or that plus P: exact
+    a.phi = fma(y, invP, a.phi);
+#pragma unroll
+    for (int i = 0; i < NL; ++i) a.limb[i] = fma(y, ml[i], a.limb[i]);
+}
+
+// minus kappa M, carry propagation (limbs to [0, 2^24), the top one keeps the sign), then the limbs packed into a
+// 320-bit two's-complement integer (compile-time shifts)
+template <int NL>
+__host__ __device__ __forceinline__ void crt_acc_finish(CrtAcc<NL> &a, const double (&Ml)[NL], unsigned long long (&w)[CRT_W32 / 2])
+{
+    const double kappa = rint(a.phi);
+    double carry = 0.0;
+    long long li[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        const double t = fma(-kappa, Ml[i], a.limb[i]) + carry;   // integers below 2^53 in magnitude: exact
+        if (i < NL - 1) {
+            carry = floor(t * 0x1p-24);
+            li[i] = (long long)(t - carry * 0x1p24);            // in [0, 2^24)
+        } else {
+            li[i] = (long long)t;                                 // signed top limb (|value| < M / 4: a small number)
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < CRT_W32 / 2; ++k) w[k] = 0ull;
+#pragma unroll
+    for (int i = 0; i < NL - 1; ++i) {                            // non-negative 24-bit fields: plain ORs
+        const int bit = 24 * i, k = bit >> 6, sh = bit & 63;
+        w[k] |= (unsigned long long)li[i] << sh;
+        if (sh > 40 && k + 1 < CRT_W32 / 2) w[k + 1] |= (unsigned long long)li[i] >> (64 - sh);
+    }
+    {   // the signed top limb: sign-extended add at its (compile-time) position
+        constexpr int bit = 24 * (NL - 1), k0 = bit >> 6, sh = bit & 63;
+        const long long T = li[NL - 1];
+        const unsigned long long ext = (unsigned long long)(T >> 63);
+        const unsigned long long lo = (unsigned long long)T << sh;
+        const unsigned long long hi = sh ? (unsigned long long)(T >> (64 - sh)) : ext;
+        unsigned long long c = 0;
+#pragma unroll
+        for (int k = 0; k < CRT_W32 / 2; ++k) {
+            const unsigned long long v = (k < k0) ? 0ull : (k == k0 ? lo : (k == k0 + 1 ? hi : ext));
+            const unsigned long long s1 = w[k] + v, c1 = s1 < v ? 1ull : 0ull;
+            const unsigned long long s2 = s1 + c, c2 = s2 < c ? 1ull : 0ull;
+            w[k] = s2;
+            c = c1 | c2;
+        }
+    }
+}
+
+// Host mirror of k_crt_finish's arithmetic over the same tables and the same routines (CPU-only check of the table
+// generator and of the reconstruction, tests/test_abi.py): random integers |S| < M_L / 4 for every L -> residues ->
+// groups -> limbs -> minus kappa M_L -> words; the 320-bit two's-complement result must be S again.  Runs every limb
+// count the kernels instantiate that can hold M_L.
+template <int NL>
+static bool crt_selftest_one(const CrtTables &t, int L, const Big &mag, bool neg)
+{
+    if (24 * NL < t.bits[L] + 1) return true;   // this limb count is not used for L
+    const int G = (L + 2) / 3, wlast = L - 3 * (G - 1);
+    CrtAcc<NL> a;
+    crt_acc_zero(a);
+    for (int b = 0; b < G; ++b) {
+        const int w = b == G - 1 ? wlast : 3;
+        double r[3] = {0, 0, 0};
+        for (int j = 0; j < 3; ++j) {
+            const uint32_t p = (uint32_t)t.p[min(3 * b + j, L - 1)];   // past the end: a valid residue, coefficient zero
+            uint32_t m = mag.mod_small(p);
+            if (neg && m) m = p - m;
+            r[j] = (double)m;
+        }
+        double ml[NL];
+        for (int i = 0; i < NL; ++i) ml[i] = t.ml[L][b][i];
+        crt_group_step<NL>(a, r[0], r[1], r[2], t.gc[L][b][0], t.gc[L][b][1], t.gc[L][b][2], t.P[b][w - 1], t.invP[b][w - 1],
+                           t.invPlow[b][w - 1], ml);
+    }
+    double Ml[NL];
+    for (int i = 0; i < NL; ++i) Ml[i] = t.Ml[L][i];
+    unsigned long long got[CRT_W32 / 2];
+    crt_acc_finish<NL>(a, Ml, got);
+    // expected: two's complement of +-mag
+    uint64_t c = neg ? 1 : 0;
+    for (int k = 0; k < CRT_W32 / 2; ++k) {
+        uint64_t word = (uint64_t)mag.w[2 * k] | ((uint64_t)mag.w[2 * k + 1] << 32);
+        if (neg) {
+            word = ~word;
+            const uint64_t s = word + c;
+            c = s < c ? 1 : 0;
+            word = s;
+        }
+        if (word != got[k]) return false;
+    }
+    return true;
+}
+
 static int crt_selftest_host(int cases, unsigned seed)
 {
     const CrtTables &t = crt_tables_host();
@@ -206,48 +323,10 @@ static int crt_selftest_host(int cases, unsigned seed)
                 }
             }
             const bool neg = (cs & 1) && mag.bitlen() > 0;
-            const int G = (L + 2) / 3, wlast = L - 3 * (G - 1);
-            uint32_t acc[CRT_W32] = {0};
-            double phi = 0.0;
-            for (int b = 0; b < G; ++b) {
-                const int w = b == G - 1 ? wlast : 3;
-                double r[3] = {0, 0, 0};
-                for (int j = 0; j < w; ++j) {
-                    const uint32_t p = (uint32_t)t.p[3 * b + j];
-                    uint32_t m = mag.mod_small(p);
-                    if (neg && m) m = p - m;
-                    r[j] = (double)m;
-                }
-                const double x = fma(r[2], t.gc[L][b][2], fma(r[1], t.gc[L][b][1], r[0] * t.gc[L][b][0]));  // < 2^34: exact
-                const double y = crt_dmod(x, t.P[b][w - 1], t.invP[b][w - 1]);
-                phi = fma(y, t.invP[b][w - 1], phi);
-                const uint32_t yb = (uint32_t)y;
-                uint64_t carry = 0;
-                for (int i = 0; i < CRT_W32; ++i) {
-                    const uint64_t v = (uint64_t)t.MP[L][b][i] * yb + acc[i] + carry;
-                    acc[i] = (uint32_t)v;
-                    carry = v >> 32;
-                }
-            }
-            const uint32_t kappa = (uint32_t)rint(phi);
-            uint64_t mc = 0, borrow = 0;
-            for (int i = 0; i < CRT_W32; ++i) {
-                const uint64_t prod = (uint64_t)t.M[L][i] * kappa + mc;
-                mc = prod >> 32;
-                const uint64_t d = (uint64_t)acc[i] - (prod & 0xffffffffull) - borrow;
-                acc[i] = (uint32_t)d;
-                borrow = (d >> 32) & 1ull;
-            }
-            // expected: two's complement of +-mag in CRT_W32 words
-            uint32_t want[CRT_W32];
-            uint64_t c = neg ? 1 : 0;
-            for (int i = 0; i < CRT_W32; ++i) {
-                const uint64_t v = (uint64_t)(neg ? ~mag.w[i] : mag.w[i]) + c;
-                want[i] = (uint32_t)v;
-                c = neg ? (v >> 32) : 0;
-            }
-            for (int i = 0; i < CRT_W32; ++i)
-                if (want[i] != acc[i]) { ++bad; break; }
+            const bool ok = crt_selftest_one<4>(t, L, mag, neg) && crt_selftest_one<6>(t, L, mag, neg) &&
+                            crt_selftest_one<8>(t, L, mag, neg) && crt_selftest_one<10>(t, L, mag, neg) &&
+                            crt_selftest_one<12>(t, L, mag, neg);
+            if (!ok) ++bad;
         }
     return bad;
 }
@@ -517,8 +596,10 @@ __global__ void __launch_bounds__(256, 1) k_gemm_crt(int n, int row_end, int ty0
 // ---------------------------------------------------------------------------------------------
 // reconstruct and round
 // ---------------------------------------------------------------------------------------------
-// NW = 32-bit words the sums are carried in (a bucket of the width of M_L): the inner loops carry no branches
-template <int NW>
+// NL = 24-bit limbs the sums are carried in (a bucket of the width of M_L): the inner loops carry no branches.
+// Thread = (group of 4 rows, column): the L words R[t][g][j] hold the residues of its 4 entries, loaded two groups of
+// moduli ahead of their use; the table entries of a group are wave-uniform scalars, read once for the four entries.
+template <int NL>
 __device__ __forceinline__ void crt_finish_body(int L, int na, int nb, int g, int gj, int row1, const unsigned *__restrict__ rp,
                                                 size_t stride, const int *__restrict__ EA, const int *__restrict__ EB,
                                                 double beta, double *__restrict__ c, long long ldc, int round_mode)
@@ -528,39 +609,19 @@ __device__ __forceinline__ void crt_finish_body(int L, int na, int nb, int g, in
 #pragma unroll
         for (int j = 0; j < 3; ++j) d[j] = rp[(size_t)min(3 * b + j, L - 1) * stride];  // past the end: a valid word, unused
     };
-    unsigned acc[4][NW];
-    double phi[4];
+    CrtAcc<NL> acc[4];
 #pragma unroll
-    for (int o = 0; o < 4; ++o) {
-        phi[o] = 0.0;
-#pragma unroll
-        for (int i = 0; i < NW; ++i) acc[o][i] = 0u;
-    }
-    // one group of moduli for the four entries: classical CRT inside the group folded with the group's weight --
-    // y_b = (r_0 c_0 + r_1 c_1 + r_2 c_2) mod P_b with c_j = gc[L][b][j] < 2^24 (zero for a modulus the last group does not
-    // use), the sum an exact integer below 2^34; three multiply-adds and ONE reduction per entry and group (the Garner
-    // form it replaces: two lazy reductions + the canonical one, ~25 fp64 instructions)
+    for (int o = 0; o < 4; ++o) crt_acc_zero(acc[o]);
     auto group = [&](int b, int w, const unsigned (&cur)[3]) {
         const double c0 = g_crt.gc[L][b][0], c1 = g_crt.gc[L][b][1], c2 = g_crt.gc[L][b][2];
-        const double Pb = g_crt.P[b][w - 1], iPb = g_crt.invP[b][w - 1];
-        unsigned mp[NW];
+        const double Pb = g_crt.P[b][w - 1], iPb = g_crt.invP[b][w - 1], iPlow = g_crt.invPlow[b][w - 1];
+        double ml[NL];
 #pragma unroll
-        for (int i = 0; i < NW; ++i) mp[i] = g_crt.MP[L][b][i];
+        for (int i = 0; i < NL; ++i) ml[i] = g_crt.ml[L][b][i];
 #pragma unroll
-        for (int o = 0; o < 4; ++o) {
-            const double r0 = (double)((cur[0] >> (8 * o)) & 255u), r1 = (double)((cur[1] >> (8 * o)) & 255u),
-                         r2 = (double)((cur[2] >> (8 * o)) & 255u);
-            const double y = crt_dmod(fma(r2, c2, fma(r1, c1, r0 * c0)), Pb, iPb);
-            phi[o] = fma(y, iPb, phi[o]);
-            const unsigned yb = (unsigned)y;
-            unsigned long long carry = 0;
-#pragma unroll
-            for (int i = 0; i < NW; ++i) {
-                const unsigned long long t = (unsigned long long)mp[i] * yb + acc[o][i] + carry;
-                acc[o][i] = (unsigned)t;
-                carry = t >> 32;
-            }
-        }
+        for (int o = 0; o < 4; ++o)
+            crt_group_step<NL>(acc[o], (double)((cur[0] >> (8 * o)) & 255u), (double)((cur[1] >> (8 * o)) & 255u),
+                               (double)((cur[2] >> (8 * o)) & 255u), c0, c1, c2, Pb, iPb, iPlow, ml);
     };
     unsigned cur[3], nx1[3], nx2[3];
     fetch(0, cur);
@@ -576,74 +637,46 @@ __device__ __forceinline__ void crt_finish_body(int L, int na, int nb, int g, in
         }
     }
     group(G - 1, wlast, cur);
+    double Ml[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) Ml[i] = g_crt.Ml[L][i];
     const int ebj = EB[gj] - nb;
-#pragma unroll 1
+#pragma unroll
     for (int o = 0; o < 4; ++o) {
         const int gi = 4 * g + o;
-        if (gi >= row1) break;
-        unsigned a10[CRT_W32];
-        double ph = phi[0];
-#pragma unroll
-        for (int i = 0; i < CRT_W32; ++i) a10[i] = i < NW ? acc[0][i] : 0u;
-#pragma unroll
-        for (int q = 1; q < 4; ++q)
-            if (o == q) {
-                ph = phi[q];
-#pragma unroll
-                for (int i = 0; i < NW; ++i) a10[i] = acc[q][i];
-            }
-        // minus kappa * M_L, over all words: a negative value comes out in two's complement
-        const unsigned kappa = (unsigned)rint(ph);
-        unsigned long long mc = 0, borrow = 0;
-#pragma unroll
-        for (int i = 0; i < CRT_W32; ++i) {
-            const unsigned long long prod = (unsigned long long)g_crt.M[L][i] * kappa + mc;
-            mc = prod >> 32;
-            const unsigned long long d = (unsigned long long)a10[i] - (prod & 0xffffffffull) - borrow;
-            a10[i] = (unsigned)d;
-            borrow = (d >> 32) & 1ull;
+        if (gi < row1) {
+            unsigned long long w5[CRT_W32 / 2];
+            crt_acc_finish<NL>(acc[o], Ml, w5);
+            const int u0 = EA[gi] - na + ebj;
+            const double s = round_mode ? wide_round_reference<CRT_W32 / 2>(w5, u0) : wide_round_sel<CRT_W32 / 2>(w5, u0);
+            double *cij = c + (long long)gi * ldc + gj;
+            *cij = (beta == 0.0) ? s : beta * (*cij) + s;
         }
-        unsigned long long w5[CRT_W32 / 2];
-#pragma unroll
-        for (int i = 0; i < CRT_W32 / 2; ++i) w5[i] = (unsigned long long)a10[2 * i] | ((unsigned long long)a10[2 * i + 1] << 32);
-        const int u0 = EA[gi] - na + ebj;
-        const double s = round_mode ? wide_round_reference<CRT_W32 / 2>(w5, u0) : wide_round_n<CRT_W32 / 2>(w5, u0);
-        double *cij = c + (long long)gi * ldc + gj;
-        *cij = (beta == 0.0) ? s : beta * (*cij) + s;
     }
 }
 
-// Two kernels (narrow sums: up to 6 words; wide: 8 or 10), each with the register budget of its widest body; the launch
-// the data does not need exits at once (an empty launch of 65536 workgroups costs ~20 us: six candidates were too many).
-template <bool WIDE>
+// One kernel per limb-count bucket (6: up to 144 bits -- 18 moduli; 8: 192 bits; 12: every L) and rounding mode, each
+// with the register budget of its own body (one kernel holding all bodies and both roundings took 191 VGPRs and spilled
+// 274 SGPRs); the launches the data does not need exit at once (an empty launch of 16384 workgroups costs ~5 us).
+template <int NL, int RM>
 __global__ void __launch_bounds__(256) k_crt_finish(int row0, int row1, int n, const int *__restrict__ info,
                                                     const int *__restrict__ EA, const int *__restrict__ EB, double beta,
-                                                    double *__restrict__ c, long long ldc, int round_mode,
+                                                    double *__restrict__ c, long long ldc,
                                                     const unsigned *__restrict__ R, int m4, int all)
 {
     // R: the residues of the row chunk that starts at row0 (m4 groups of four rows)
     if (info[INFO_PATH] != PATH_CRT) return;
     const int L = info[INFO_CRT_L], na = info[INFO_CRT_NA], nb = info[INFO_CRT_NB];
-    // words that hold the sum of up to 13 terms below M_L each (4 bits of headroom)
-    const int nw = (g_crt.bits[L] + 1 + 4 + 31) >> 5;
-    if (!all && (nw > 6) != WIDE) return;
+    // 24-bit limbs that hold M_L (the top limb, a double, takes the headroom of the 13-term sums)
+    const int nl = (g_crt.bits[L] + 1 + 23) / 24;
+    if (!all && (nl <= 6 ? 6 : (nl <= 8 ? 8 : CRT_NL24)) != NL) return;
     const long long loc = (long long)blockIdx.x * 256 + threadIdx.x;
     const int groups = (row1 - row0 + 3) >> 2;
     if (loc >= (long long)groups * n) return;
     const int gl = (int)(loc / n), g = (row0 >> 2) + gl, gj = (int)(loc % n);
     const size_t stride = (size_t)m4 * n;
     const unsigned *rp = R + (size_t)gl * n + gj;
-#define CRT_FIN(NW) crt_finish_body<NW>(L, na, nb, g, gj, row1, rp, stride, EA, EB, beta, c, ldc, round_mode)
-    if constexpr (WIDE) {
-        if (nw <= 8 && !all) CRT_FIN(8);
-        else CRT_FIN(CRT_W32);
-    } else {
-        if (nw <= 3) CRT_FIN(3);
-        else if (nw == 4) CRT_FIN(4);
-        else if (nw == 5) CRT_FIN(5);
-        else CRT_FIN(6);
-    }
-#undef CRT_FIN
+    crt_finish_body<NL>(L, na, nb, g, gj, row1, rp, stride, EA, EB, beta, c, ldc, RM);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -773,14 +806,21 @@ hipError_t exgemm_crt_rows(const I8Plan &p, int row0, int row1, hipStream_t st)
                                    p.R, p.m4, mod0);
             }
         const long long groups = (c1 - c0 + 3) / 4;
-#define CRT_FIN(WIDE, ALL)                                                                                               \
-    hipLaunchKernelGGL((k_crt_finish<WIDE>), dim3((unsigned)((groups * p.n + 255) / 256)), dim3(256), 0, st, c0, c1,      \
-                       p.n, p.info, p.EA, p.EB, p.beta, p.c, (long long)p.ldc, p.round_mode, p.R, p.m4, ALL)
+#define CRT_FIN(NLB, ALL)                                                                                                \
+    do {                                                                                                                 \
+        if (p.round_mode)                                                                                                \
+            hipLaunchKernelGGL((k_crt_finish<NLB, 1>), dim3((unsigned)((groups * p.n + 255) / 256)), dim3(256), 0, st, c0, \
+                               c1, p.n, p.info, p.EA, p.EB, p.beta, p.c, (long long)p.ldc, p.R, p.m4, ALL);              \
+        else                                                                                                             \
+            hipLaunchKernelGGL((k_crt_finish<NLB, 0>), dim3((unsigned)((groups * p.n + 255) / 256)), dim3(256), 0, st, c0, \
+                               c1, p.n, p.info, p.EA, p.EB, p.beta, p.c, (long long)p.ldc, p.R, p.m4, ALL);              \
+    } while (0)
         if (groups * p.n < (1 << 18)) {
-            CRT_FIN(true, 1);  // small products are launch-bound: one kernel (10 words) for every width
+            CRT_FIN(CRT_NL24, 1);  // small products are launch-bound: one kernel (12 limbs) for every width
         } else {
-            CRT_FIN(false, 0);
-            CRT_FIN(true, 0);
+            CRT_FIN(6, 0);
+            CRT_FIN(8, 0);
+            CRT_FIN(CRT_NL24, 0);
         }
 #undef CRT_FIN
     }

@@ -148,6 +148,51 @@ __device__ inline double wide_round_n(const unsigned long long (&in)[NW], int un
     return neg ? -r : r;
 }
 
+// The same rounding without dynamically indexed arrays (wide_round_n's m[top] puts its words in scratch memory): the
+// leading word, the word below it and the sticky OR of the rest are picked by select chains over the unrolled words.
+template <int NW>
+__device__ __forceinline__ double wide_round_sel(const unsigned long long (&in)[NW], int unit_exp)
+{
+    unsigned long long m[NW];
+    const bool neg = (long long)in[NW - 1] < 0;
+    {
+        unsigned long long c = neg ? 1 : 0, cn;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            m[i] = neg ? __builtin_addcll(~in[i], 0ull, c, &cn) : in[i];
+            c = neg ? cn : 0;
+        }
+    }
+    unsigned long long hi = 0, below = 0;
+    int top = 0;
+    bool f1 = false, f2 = false, rest = false;  // f1: leading word found in an earlier step; f2: at least two steps earlier
+#pragma unroll
+    for (int i = NW - 1; i >= 0; --i) {
+        const bool nz = m[i] != 0;
+        const bool take = !f1 && nz;
+        hi = take ? m[i] : hi;
+        below = take ? (i > 0 ? m[i - 1] : 0ull) : below;
+        top = take ? i : top;
+        rest = rest || (f2 && nz);
+        f2 = f1;
+        f1 = f1 || take;
+    }
+    if (hi == 0) return 0.0;
+    const int lz = __builtin_clzll(hi);
+    const int msb = 64 * top + 63 - lz;
+    double r;
+    if (msb <= 52) {
+        r = ldexp((double)m[0], unit_exp);
+    } else {
+        const unsigned long long w = lz ? ((hi << lz) | (below >> (64 - lz))) : hi;
+        const bool sticky = (w & 0x3ffull) != 0 || (lz ? (below << lz) != 0 : below != 0) || rest;
+        unsigned long long mant = w >> 11;
+        if (((w >> 10) & 1ull) && (sticky || (mant & 1ull))) mant += 1;  // may reach 2^53: still exact in fp64
+        r = ldexp((double)mant, msb - 52 + unit_exp);
+    }
+    return neg ? -r : r;
+}
+
 // The reference's rounding on the same integer: cut value = W * 2^unit_exp into the canonical 41 x 52-bit limbs
 // (limb j = bits [52(j-21), 52(j-20)) of the value, the top limb signed; superaccumulator.cpp:14-22) and run its
 // Round() (round_reference, superacc.hip.h).  Bits of the value below 2^-1092 cannot occur on this path (|e| <= 300).
