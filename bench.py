@@ -68,6 +68,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary line items (ExDOT, BLAS2/3, host API)")
     ap.add_argument("--skip-blas23", action="store_true", help="skip the ExGEMV / ExGEMM / ExTRSV line items")
+    ap.add_argument("--blas23-timeout", type=float, default=240.0,
+                    help="N > 1: seconds the BLAS2/3 items (which post collectives) may take before rank 0 prints the line "
+                         "without them and the ranks exit; 0 = no limit")
     ap.add_argument("--no-host-api", action="store_true",
                     help="skip the host-pointer exsum() line item (its 64 MiB chunk launches of k_exsum would dilute the "
                          "per-kernel averages of a rocprofv3 --stats run)")
@@ -746,6 +749,80 @@ def main():
 
     head, keep = leg(args.op, True)
 
+    def emit(secondary, blas23, host_api, extra=None):
+        """rank 0: assemble and print THE JSON line from what has been measured"""
+        if rank == 0:
+            opname = f"Ex{args.op[2:].upper()}"
+            if world == 1:
+                shape = f"n=2^{args.log2n}"
+                par = "single"
+            elif strong:
+                shape = f"ONE vector of n=2^{args.log2n} partitioned n/{world} (exblas_shard_range)"
+                par = f"shard{world} of one vector, 576-byte digit set all-reduced per step"
+            else:
+                shape = f"n=2^{args.log2n} per GPU ({world}*2^{args.log2n} in all)"
+                par = f"shard{world}, 2^{args.log2n} elements per GPU, 576-byte digit set all-reduced per step"
+            out = {
+                "metric": f"{opname} fp64 Gelem/s at n=2^{args.log2n} (bit-exact vs CPU superaccumulator/MPFR)",
+                "value": head["value"],
+                "unit": "Gelem/s",
+                "n_gpus": n_ranks_seen,
+                "steps": args.steps,
+                "warmup": args.warmup,
+                "ms_per_step": head["ms_per_step"],
+                "higher_is_better": True,
+                "scaling": head["scaling"],
+                "vs_baseline": None,
+                "dtype": "f64",
+                "data": f"synthetic ({args.kind} p0={args.p0:g} p1={args.p1:g}, counter-based generator, {nrot} distinct "
+                        f"vectors, seeds 1,3,5,...)",
+                "transport": transport,
+                "config": {"workload": f"{opname} {shape} fp64 {args.kind}(c={args.p0:g}), fpe={args.fpe} early_exit={ee}, "
+                                       f"{world}xMI355X, inputs resident in HBM, steps rotate over {nrot} distinct vectors",
+                           "n_total": head["n_total"], "fpe": args.fpe, "early_exit": ee, "parallelism": par},
+            }
+            for k in ("roofline", "result", "result_bits", "result_bits_reference_rounding", "limbs_crc", "weak",
+                      "cpu_baseline", "bit_exact_vs_cpu", "bit_exact_detail"):
+                if k in head:
+                    out[k] = head[k]
+            if "cpu_baseline" in head:
+                out["cpu_baseline_at_cgroup_quota_Gelems"] = head["cpu_baseline"]["value_at_cgroup_quota"]
+            if secondary:
+                out["exdot"] = secondary
+            if blas23:
+                gv, gm = blas23["exgemv"], blas23["exgemm"]
+                gv["GBs"] = gv["bytes"] / (gv["ms"] * 1e-3) / 1e9
+                gv["frac_hbm_peak"] = gv["GBs"] / HBM_PEAK_GBS
+                gv["frac_hbm_peak_T"] = gv["bytes"] / (gv["ms_T"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+                gv["frac_hbm_peak_superacc_only"] = gv["bytes"] / (gv["ms_superacc_only"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+                # roofline.frac = what the matrix pipe that does the work is asked to do / its peak: every element pair
+                # costs products_per_pair multiply-adds of the MFMA type the path uses (int8 residues or digits: 5 Pop/s
+                # dense; fp64 slices: 78.6 TFLOP/s).  frac_2mnk (SURVEY 8(d): algorithmic 2mnk flop / the fp64 matrix
+                # peak) is kept beside it under its own name: it can exceed 1 because no fp64 unit does the work.
+                t2 = gm["flop_2mnk"] / (gm["ms"] * 1e-3) / 1e12
+                prods = gm.get("products_per_pair") or gm["slices"] ** 2
+                issued = t2 * prods
+                i8 = str(gm.get("path", "")).startswith("mfma_i8")
+                peak_issue = (I8_MFMA_PEAK_TOPS if i8 else F64_MFMA_PEAK_TF) * world
+                gm["TFLOPs_2mnk"] = t2
+                gm["roofline"] = {"bound": "mfma", "achieved": issued, "peak": peak_issue,
+                                  "unit": "Top/s (int8 multiply-add = 2 op)" if i8 else "TFLOP/s",
+                                  "frac": issued / peak_issue,
+                                  "frac_2mnk": t2 / (F64_MFMA_PEAK_TF * world),
+                                  "frac_2mnk_note": "algorithmic 2mnk flop / time / fp64 matrix peak: NOT a utilisation",
+                                  "traffic": load_traffic(args.traffic_json, GEMM_KERNEL.get(gm.get("path"), "k_gemm")),
+                                  "kernel": GEMM_KERNEL.get(gm.get("path"), "k_gemm"),
+                                  "note": "whole call (scans, residues, contraction, reconstruction); the contraction "
+                                          "kernel alone: profiles/ kernel stats"}
+                out["exgemv"] = gv
+                out["exgemm"] = gm
+                out["extrsv"] = blas23["extrsv"]
+            if host_api:
+                out["host_api"] = host_api
+            if extra:
+                out.update(extra)
+            print(json.dumps(out), flush=True)
+
     secondary = None
     blas23 = None
     host_api = None
@@ -755,7 +832,25 @@ def main():
         secondary["metric"] = "ExDOT fp64 Gelem/s"
         # BASELINE configs 4 and 5 on the same box (kernel-chain time by HIP events; parity is covered by tests/)
         if not args.skip_blas23:
+            # N > 1: the BLAS2/3 items include collectives that have never met real links (B broadcast, chunked all-gather
+            # of C on a side stream).  Should they hang, the headline must not hang with them: after --blas23-timeout
+            # seconds rank 0 prints the line with what it has and every rank leaves.
+            dog = None
+            if world > 1 and args.blas23_timeout > 0:
+                import threading
+
+                def bail():
+                    sys.stderr.write(f"[bench] rank {rank}: BLAS2/3 items did not finish in {args.blas23_timeout} s\n")
+                    sys.stderr.flush()
+                    if rank == 0:
+                        emit(secondary, None, None, {"blas23_timed_out_after_s": args.blas23_timeout})
+                    os._exit(0)
+                dog = threading.Timer(args.blas23_timeout, bail)
+                dog.daemon = True
+                dog.start()
             blas23 = bench_blas23(ex, torch, comm, world, rank)
+            if dog is not None:
+                dog.cancel()
         if blas23 and world > 1:
             gm = blas23["exgemm"]
             gvm, gmm, gmg = reduce_max(blas23["exgemv"]["ms"], gm["ms"], gm.get("ms_gathered", 0.0))
@@ -771,75 +866,7 @@ def main():
             host_api = bench_host_api(ex, torch, keep, args.fpe, ee)
     del keep
 
-    if rank == 0:
-        opname = f"Ex{args.op[2:].upper()}"
-        if world == 1:
-            shape = f"n=2^{args.log2n}"
-            par = "single"
-        elif strong:
-            shape = f"ONE vector of n=2^{args.log2n} partitioned n/{world} (exblas_shard_range)"
-            par = f"shard{world} of one vector, 576-byte digit set all-reduced per step"
-        else:
-            shape = f"n=2^{args.log2n} per GPU ({world}*2^{args.log2n} in all)"
-            par = f"shard{world}, 2^{args.log2n} elements per GPU, 576-byte digit set all-reduced per step"
-        out = {
-            "metric": f"{opname} fp64 Gelem/s at n=2^{args.log2n} (bit-exact vs CPU superaccumulator/MPFR)",
-            "value": head["value"],
-            "unit": "Gelem/s",
-            "n_gpus": n_ranks_seen,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": head["ms_per_step"],
-            "higher_is_better": True,
-            "scaling": head["scaling"],
-            "vs_baseline": None,
-            "dtype": "f64",
-            "data": f"synthetic ({args.kind} p0={args.p0:g} p1={args.p1:g}, counter-based generator, {nrot} distinct "
-                    f"vectors, seeds 1,3,5,...)",
-            "transport": transport,
-            "config": {"workload": f"{opname} {shape} fp64 {args.kind}(c={args.p0:g}), fpe={args.fpe} early_exit={ee}, "
-                                   f"{world}xMI355X, inputs resident in HBM, steps rotate over {nrot} distinct vectors",
-                       "n_total": head["n_total"], "fpe": args.fpe, "early_exit": ee, "parallelism": par},
-        }
-        for k in ("roofline", "result", "result_bits", "result_bits_reference_rounding", "limbs_crc", "weak",
-                  "cpu_baseline", "bit_exact_vs_cpu", "bit_exact_detail"):
-            if k in head:
-                out[k] = head[k]
-        if "cpu_baseline" in head:
-            out["cpu_baseline_at_cgroup_quota_Gelems"] = head["cpu_baseline"]["value_at_cgroup_quota"]
-        if secondary:
-            out["exdot"] = secondary
-        if blas23:
-            gv, gm = blas23["exgemv"], blas23["exgemm"]
-            gv["GBs"] = gv["bytes"] / (gv["ms"] * 1e-3) / 1e9
-            gv["frac_hbm_peak"] = gv["GBs"] / HBM_PEAK_GBS
-            gv["frac_hbm_peak_T"] = gv["bytes"] / (gv["ms_T"] * 1e-3) / 1e9 / HBM_PEAK_GBS
-            gv["frac_hbm_peak_superacc_only"] = gv["bytes"] / (gv["ms_superacc_only"] * 1e-3) / 1e9 / HBM_PEAK_GBS
-            # roofline.frac = what the matrix pipe that does the work is asked to do / its peak: every element pair
-            # costs products_per_pair multiply-adds of the MFMA type the path uses (int8 residues or digits: 5 Pop/s
-            # dense; fp64 slices: 78.6 TFLOP/s).  frac_2mnk (algorithmic 2mnk flop / the fp64 matrix
-            # peak) is kept beside it under its own name: it can exceed 1 because no fp64 unit does the work.
-            t2 = gm["flop_2mnk"] / (gm["ms"] * 1e-3) / 1e12
-            prods = gm.get("products_per_pair") or gm["slices"] ** 2
-            issued = t2 * prods
-            i8 = str(gm.get("path", "")).startswith("mfma_i8")
-            peak_issue = (I8_MFMA_PEAK_TOPS if i8 else F64_MFMA_PEAK_TF) * world
-            gm["TFLOPs_2mnk"] = t2
-            gm["roofline"] = {"bound": "mfma", "achieved": issued, "peak": peak_issue,
-                              "unit": "Top/s (int8 multiply-add = 2 op)" if i8 else "TFLOP/s",
-                              "frac": issued / peak_issue,
-                              "frac_2mnk": t2 / (F64_MFMA_PEAK_TF * world),
-                              "frac_2mnk_note": "algorithmic 2mnk flop / time / fp64 matrix peak: NOT a utilisation",
-                              "traffic": load_traffic(args.traffic_json, GEMM_KERNEL.get(gm.get("path"), "k_gemm")),
-                              "kernel": GEMM_KERNEL.get(gm.get("path"), "k_gemm"),
-                              "note": "whole call (scans, residues, contraction, reconstruction); the contraction "
-                                      "kernel alone: profiles/ kernel stats"}
-            out["exgemv"] = gv
-            out["exgemm"] = gm
-            out["extrsv"] = blas23["extrsv"]
-        if host_api:
-            out["host_api"] = host_api
-        print(json.dumps(out), flush=True)
+    emit(secondary, blas23, host_api)
     if comm is not None:
         comm.destroy()
     if dist is not None and dist.is_initialized():

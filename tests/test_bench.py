@@ -73,3 +73,16 @@ def test_strong_scaling_bits_identical_across_rank_counts():
             assert b["bit_exact_vs_cpu"] is True, (n, b.get("bit_exact_detail"))
             for key in ("result_bits", "result_bits_reference_rounding", "limbs_crc"):
                 assert a[key] == b[key], (n, key, a[key], b[key])
+
+
+@pytest.mark.gpu
+def test_blas23_watchdog_keeps_the_headline():
+    """N > 1: the BLAS2/3 items post collectives; if they do not finish in --blas23-timeout seconds rank 0 still prints the
+    line (headline + ExDOT, bit checks included) and every rank leaves.  Forced here with a timeout no ExGEMV can meet."""
+    r = _run(["--gpus", "2", "--log2n", "21", "--steps", "4", "--warmup", "1", "--prewarm-ms", "0", "--rotate", "2",
+              "--no-host-api", "--blas23-timeout", "0.05"], {"EXBLAS_BENCH_BACKEND": "gloo"})
+    js = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(js) == 1, (r.returncode, r.stdout[-1500:], r.stderr[-3000:])
+    ln = json.loads(js[0])
+    assert ln["n_gpus"] == 2 and ln["bit_exact_vs_cpu"] is True and ln["exdot"]["bit_exact_vs_cpu"] is True
+    assert ln["blas23_timed_out_after_s"] == 0.05 and "exgemm" not in ln
