@@ -270,6 +270,36 @@ def test_exgemm_residue_row_chunks(ex, oracle, ta):
         assert (_bits(got[r0 * n:(r0 + rows) * n]) == _bits(want)).all(), (ta, r0)
 
 
+def test_exgemm_residue_chunks_tiles_and_k_passes_together(ex, oracle):
+    """Several row chunks (m > 3072) x several 256-column workgroup tiles x two contraction launches per modulus
+    (k > 8192: residues of the second k block added modulo p to those of the first) in ONE call, ragged in every
+    dimension, alpha / beta other than 0 / 1: residues == digit slices everywhere, rows at the chunk boundaries == oracle."""
+    import torch
+    lib = ex.load_library()
+    m, n, k = 2 * 2048 + 130, 3 * 256 + 37, 8192 + 801
+    A = ex.gen_dev("fpuniform_signed", m * k, 181, 12, 6)
+    B = ex.gen_dev("fpuniform_signed", k * n, 182, 10, 5)
+    C0 = ex.gen_dev("fpuniform_signed", m * n, 183, 10, 5)
+    outs = {}
+    try:
+        for path in (4, 2):
+            lib.exblas_set_gemm_path(path)
+            C = C0.clone()
+            ex.exgemm_dev("N", "N", m, n, k, -0.5, A, k, B, n, 2.0, C, n, 8, True)
+            torch.cuda.synchronize()
+            assert gemm_info(lib)[0] == path
+            outs[path] = C
+    finally:
+        lib.exblas_set_gemm_path(0)
+    assert torch.equal(outs[4].view(torch.int64), outs[2].view(torch.int64))
+    ha, hb, hc0, got = A.cpu().numpy(), B.cpu().numpy(), C0.cpu().numpy(), outs[4].cpu().numpy()
+    for r0 in (2045, 4094, m - 5):
+        rows = min(5, m - r0)
+        want = oracle.exgemm("N", "N", rows, n, k, -0.5, ha[r0 * k:(r0 + rows) * k], k, hb, n, 2.0,
+                             hc0[r0 * n:(r0 + rows) * n].copy(), n, 0)
+        assert (_bits(got[r0 * n:(r0 + rows) * n]) == _bits(want)).all(), r0
+
+
 def test_workspace_failed_growth_leaves_context_intact(ex, oracle):
     """A reservation that cannot be met must not touch the live workspace: afterwards it is neither parked (a later
     exblas_release_retired_workspaces() would free memory the next call launches into) nor resized, the failed
