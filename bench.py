@@ -82,16 +82,12 @@ def parse():
 def timed_steps(ex, torch, dist, comm, op, buffers, fpe, ee, steps, warmup, world, rec, prewarm_ms=0.0):
     """Returns (wall seconds for `steps` steps, mean ms of the streaming kernel alone).
 
-    With a communicator (N > 1, or the one-rank rehearsal): two-deep pipeline on two HIP streams -- the streaming kernel
-    of step i fills accumulator slot i mod 2 on the main stream; the step's second half (normalise, all-reduce,
-    carry-propagate + round into a record) runs on a side stream beside the streaming kernel of step i+1.  Without
-    one (N == 1): streaming kernel + finalize back to back on one stream.  Either way every step is carried to its
+    With a communicator (N > 1, or the one-rank rehearsal): two-deep pipeline on two HIP streams inside ONE library call
+    per step -- the streaming kernel of step i fills accumulator slot i mod 2 on the main stream; the step's second half
+    (normalise, all-reduce, carry-propagate + round into a record) runs on the communicator's side stream beside the
+    streaming kernel of step i+1.  Without one (N == 1): streaming kernel + finalize back to back on one stream.  Either way every step is carried to its
     final rounded result inside the timed region (drain() before the closing synchronize)."""
-    main = torch.cuda.current_stream()
-    side = torch.cuda.Stream()
     ring = [rec] + [ex.new_record_buffer() for _ in range(3)]
-    ev_acc = [torch.cuda.Event(), torch.cuda.Event()]        # streaming kernel of the slot enqueued
-    ev_done = [None, None]                                   # the slot's accumulators are zero again
     state = {"i": 0, "last": rec}
     nbuf = len(buffers)
 
@@ -116,36 +112,23 @@ def timed_steps(ex, torch, dist, comm, op, buffers, fpe, ee, steps, warmup, worl
     def one_step(e0=None, e1=None):
         if comm is None:
             return one_step_single(e0, e1)
+        # ONE library call per step (exblas_ex*_allreduce_pipelined_dev): streaming kernel on this stream into the slot
+        # the communicator alternates; normalise + all-reduce + round on its side stream beside the next step's kernel.
+        # (The same pipeline driven from Python -- slot select, two event records, a stream switch, three launches --
+        # cost ~10 us of host time per step more than the 46 us kernel of a 2^25-element shard.)
         i = state["i"]
         state["i"] += 1
-        slot = i & 1
         r = ring[i % len(ring)]
-        if ev_done[slot] is not None:
-            main.wait_event(ev_done[slot])
-        ex.set_accumulator_slot(slot)
-        if e0 is not None:
-            e0.record()
         b = buffers[i % nbuf]
         if op == "exsum":
-            ex.exsum_accumulate_dev(b[0], fpe, ee)
+            ex.exsum_allreduce_pipelined(comm, b[0], fpe, ee, out=r, ev_start=e0, ev_end=e1)
         else:
-            ex.exdot_accumulate_dev(b[0], b[1], fpe, ee)
-        if e1 is not None:
-            e1.record()
-        ev_acc[slot].record(main)
-        with torch.cuda.stream(side):
-            side.wait_event(ev_acc[slot])
-            if comm is not None:
-                ex.allreduce_finish(comm, out=r)
-            else:
-                ex.finish_dev(out=r)
-            if ev_done[slot] is None:
-                ev_done[slot] = torch.cuda.Event()
-            ev_done[slot].record(side)
+            ex.exdot_allreduce_pipelined(comm, b[0], b[1], fpe, ee, out=r, ev_start=e0, ev_end=e1)
         state["last"] = r
 
     def drain():
-        main.wait_stream(side)
+        if comm is not None:
+            ex.pipeline_drain(comm)
 
     # clock ramp-up: untimed steps for about prewarm_ms.  With several ranks the number of steps (= collectives) must
     # be the same everywhere, so the ranks vote after every batch whether to go on.
@@ -166,6 +149,9 @@ def timed_steps(ex, torch, dist, comm, op, buffers, fpe, ee, steps, warmup, worl
         one_step()
     drain()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    for a_, b_ in ev:        # a torch event gets its handle at its first record(): the library records them by handle
+        a_.record()
+        b_.record()
     stride = nbuf + 1 if nbuf > 1 else 4
     torch.cuda.synchronize()
     if world > 1:
@@ -189,7 +175,6 @@ def timed_steps(ex, torch, dist, comm, op, buffers, fpe, ee, steps, warmup, worl
     dt = time.perf_counter() - t0
     timed = [p for i, p in enumerate(ev) if not (i % stride and steps >= 2 * stride)]
     kms = sum(a.elapsed_time(b) for a, b in timed) / max(len(timed), 1)
-    ex.set_accumulator_slot(0)
     if state["last"] is not rec:
         rec.copy_(state["last"])
     return dt, kms

@@ -38,6 +38,7 @@ C_ABI_SYMBOLS = [
     "exblas_exgemv_sharded_dev", "exblas_exgemm_sharded_dev", "exblas_last_gemm_info", "exblas_set_gemm_max_slices",
     "exblas_set_gemm_max_moduli", "exblas_crt_selftest",
     "exblas_set_host_devices", "exblas_workspace_bytes",
+    "exblas_exsum_allreduce_pipelined_dev", "exblas_exdot_allreduce_pipelined_dev", "exblas_pipeline_drain_dev",
     "exblas_ctx_create", "exblas_ctx_destroy", "exblas_exsum_ctx", "exblas_exdot_ctx", "exblas_exsum_accumulate_ctx",
     "exblas_exdot_accumulate_ctx", "exblas_finish_ctx", "exblas_exgemv_ctx", "exblas_extrsv_ctx", "exblas_exgemm_ctx",
     "exblas_reserve_workspace_ctx", "exblas_workspace_bytes_ctx", "exblas_last_gemm_info_ctx",
@@ -152,6 +153,9 @@ def load_library():
     L.exblas_exsum_allreduce_dev.argtypes = [vp, vp, i64, i64, i32, i32, vp, vp]
     L.exblas_exdot_allreduce_dev.argtypes = [vp, vp, i64, vp, i64, i64, i32, i32, vp, vp]
     L.exblas_allreduce_finish_dev.argtypes = [vp, vp, vp]
+    L.exblas_exsum_allreduce_pipelined_dev.argtypes = [vp, vp, i64, i64, i32, i32, vp, vp, vp, vp]
+    L.exblas_exdot_allreduce_pipelined_dev.argtypes = [vp, vp, i64, vp, i64, i64, i32, i32, vp, vp, vp, vp]
+    L.exblas_pipeline_drain_dev.argtypes = [vp, vp]
     L.exblas_exgemv_sharded_dev.argtypes = [vp, C.c_char, i32, i32, dbl, vp, i32, vp, i32, i32, dbl, vp, i32, i32, i32,
                                             i32, vp]
     L.exblas_exgemm_sharded_dev.argtypes = [vp, C.c_char, C.c_char, i32, i32, i32, dbl, vp, i32, vp, i32, i32, dbl,
@@ -505,4 +509,5 @@ def exgemm(transa, transb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, fpe, ea
 
 
 from .dist import (Comm, exsum_allreduce, exdot_allreduce, allreduce_finish, allreduce_record,  # noqa: E402,F401
-                   shard_range, row_block, exgemv_sharded, exgemm_sharded)
+                   shard_range, row_block, exgemv_sharded, exgemm_sharded, exsum_allreduce_pipelined,
+                   exdot_allreduce_pipelined, pipeline_drain)

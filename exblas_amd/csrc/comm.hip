@@ -103,6 +103,11 @@ struct exblas_comm {
     // overlap machinery of the sharded GEMM: a side stream for the all-gather pieces + events
     hipStream_t side = nullptr;
     hipEvent_t ev_chunk = nullptr, ev_done = nullptr;
+    // pipelined reductions (exblas_ex*_allreduce_pipelined_dev): per accumulator slot, "streaming kernel enqueued" and
+    // "slot's accumulators zero again"
+    hipEvent_t ev_acc[2] = {nullptr, nullptr}, ev_zero[2] = {nullptr, nullptr};
+    bool zero_pending[2] = {false, false};
+    int pipe_slot = 0;
     // host transport bounce buffer (pinned)
     void *bounce = nullptr;
     size_t bounce_bytes = 0;
@@ -130,6 +135,19 @@ static int comm_side(exblas_comm *cm)
         if ((e = hipEventCreateWithFlags(&cm->ev_chunk, hipEventDisableTiming)) != hipSuccess) return (int)e;
         if ((e = hipEventCreateWithFlags(&cm->ev_done, hipEventDisableTiming)) != hipSuccess) return (int)e;
     }
+    return 0;
+}
+
+static int comm_pipe(exblas_comm *cm)
+{
+    int rc = comm_side(cm);
+    if (rc) return rc;
+    for (int s = 0; s < 2; ++s)
+        if (!cm->ev_acc[s]) {
+            hipError_t e = hipEventCreateWithFlags(&cm->ev_acc[s], hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&cm->ev_zero[s], hipEventDisableTiming);
+            if (e != hipSuccess) return (int)e;
+        }
     return 0;
 }
 
@@ -316,6 +334,10 @@ int exblas_comm_destroy(exblas_comm_t *cm)
         (void)hipStreamDestroy(cm->side);
         (void)hipEventDestroy(cm->ev_chunk);
         (void)hipEventDestroy(cm->ev_done);
+        for (int s = 0; s < 2; ++s) {
+            if (cm->ev_acc[s]) (void)hipEventDestroy(cm->ev_acc[s]);
+            if (cm->ev_zero[s]) (void)hipEventDestroy(cm->ev_zero[s]);
+        }
     }
     if (cm->bounce) (void)hipHostFree(cm->bounce);
     int rc = 0;
@@ -347,6 +369,76 @@ int exblas_allreduce_finish_dev(exblas_comm_t *cm, void *stream, int64_t *d_out)
     if (rc) return rc;
     // in place: k_finalize reads every input word before it writes the first output word
     return (int)finalize_sets((const long long *)d_out + OUT_DIGITS, 1, 0u, st, (long long *)d_out);
+}
+
+// ---- pipelined form: the second half of reduction i runs on the communicator's side stream beside the streaming
+// kernel of reduction i + 1 (two accumulator slots, alternating) -- one library call per reduction
+static int pipelined_step(exblas_comm_t *cm, const double *d_a, int64_t inca, const double *d_b, int64_t incb, int64_t n,
+                          int fpe, int early_exit, hipStream_t st, int64_t *d_out, hipEvent_t t0, hipEvent_t t1)
+{
+    if (!cm) return (int)hipErrorInvalidValue;
+    std::lock_guard<std::mutex> lk(cm->mu);
+    int rc = comm_pipe(cm);
+    if (rc) return rc;
+    const int slot = cm->pipe_slot;
+    cm->pipe_slot ^= 1;
+    hipError_t e = hipSuccess;
+    if (cm->zero_pending[slot]) {   // the slot's previous reduction (two calls ago) must have left it zero
+        // normally long done: then no wait packet goes into the stream (one packet between two streaming kernels costs
+        // ~3 us); the query is not legal while the stream is being captured -- there the dependency is always recorded
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        const bool capturing = hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+        if (capturing || hipEventQuery(cm->ev_zero[slot]) != hipSuccess) e = hipStreamWaitEvent(st, cm->ev_zero[slot], 0);
+        (void)hipGetLastError();    // hipEventQuery's hipErrorNotReady is not an error
+    }
+    if (e != hipSuccess) return (int)e;
+    if ((rc = exblas_set_accumulator_slot(slot)) != 0) return rc;
+    if (t0 && (e = hipEventRecord(t0, st)) != hipSuccess) return (int)e;
+    rc = d_b ? exblas_exdot_accumulate_dev(d_a, inca, d_b, incb, n, fpe, early_exit, st)
+             : exblas_exsum_accumulate_dev(d_a, n, inca, fpe, early_exit, st);
+    if (rc) return rc;
+    if (t1 && (e = hipEventRecord(t1, st)) != hipSuccess) return (int)e;
+    e = hipEventRecord(cm->ev_acc[slot], st);
+    if (e == hipSuccess) e = hipStreamWaitEvent(cm->side, cm->ev_acc[slot], 0);
+    if (e != hipSuccess) return (int)e;
+    // normalise the slot (leaves it zero), all-reduce, carry-propagate + round: on the side stream
+    if ((rc = exblas_finish_dev(cm->side, d_out)) != 0) return rc;
+    if ((rc = comm_allreduce_i64(cm, (long long *)d_out + OUT_DIGITS, SET_WORDS, cm->side)) != 0) return rc;
+    if ((rc = (int)finalize_sets((const long long *)d_out + OUT_DIGITS, 1, 0u, cm->side, (long long *)d_out)) != 0) return rc;
+    e = hipEventRecord(cm->ev_zero[slot], cm->side);
+    cm->zero_pending[slot] = e == hipSuccess;
+    return (int)e;
+}
+
+int exblas_exsum_allreduce_pipelined_dev(exblas_comm_t *cm, const double *d_a_local, int64_t n_local, int64_t inca, int fpe,
+                                         int early_exit, void *stream, int64_t *d_out, void *ev_kernel_start,
+                                         void *ev_kernel_end)
+{
+    return pipelined_step(cm, d_a_local, inca, nullptr, 1, n_local, fpe, early_exit, (hipStream_t)stream, d_out,
+                          (hipEvent_t)ev_kernel_start, (hipEvent_t)ev_kernel_end);
+}
+
+int exblas_exdot_allreduce_pipelined_dev(exblas_comm_t *cm, const double *d_a_local, int64_t inca, const double *d_b_local,
+                                         int64_t incb, int64_t n_local, int fpe, int early_exit, void *stream,
+                                         int64_t *d_out, void *ev_kernel_start, void *ev_kernel_end)
+{
+    return pipelined_step(cm, d_a_local, inca, d_b_local, incb, n_local, fpe, early_exit, (hipStream_t)stream, d_out,
+                          (hipEvent_t)ev_kernel_start, (hipEvent_t)ev_kernel_end);
+}
+
+int exblas_pipeline_drain_dev(exblas_comm_t *cm, void *stream)
+{
+    if (!cm) return (int)hipErrorInvalidValue;
+    std::lock_guard<std::mutex> lk(cm->mu);
+    hipError_t e = hipSuccess;
+    for (int s = 0; s < 2 && e == hipSuccess; ++s)
+        if (cm->zero_pending[s]) {
+            e = hipStreamWaitEvent((hipStream_t)stream, cm->ev_zero[s], 0);
+            cm->zero_pending[s] = false;
+        }
+    cm->pipe_slot = 0;
+    const int rc = exblas_set_accumulator_slot(0);
+    return e != hipSuccess ? (int)e : rc;
 }
 
 int exblas_exsum_allreduce_dev(exblas_comm_t *cm, const double *d_a_local, int64_t n_local, int64_t inca, int fpe,

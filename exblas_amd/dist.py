@@ -187,6 +187,45 @@ def exdot_allreduce(comm, x_local, y_local, fpe=8, early_exit=True, out=None):
     return out
 
 
+def _evh(ev):
+    return C.c_void_p(ev.cuda_event) if ev is not None else None
+
+
+def exsum_allreduce_pipelined(comm, x_local, fpe=8, early_exit=True, out=None, ev_start=None, ev_end=None):
+    """One call per reduction; the second half overlaps the next call's streaming kernel (see
+    ``exblas_exsum_allreduce_pipelined_dev``).  ev_start / ev_end: torch.cuda.Event (created with enable_timing=True and
+    already recorded once, so that they have a handle) recorded around the streaming kernel."""
+    from . import load_library, _check, _require_gpu, new_record_buffer
+    torch = _require_gpu()
+    if out is None:
+        out = new_record_buffer()
+    _check(load_library().exblas_exsum_allreduce_pipelined_dev(comm.handle, C.c_void_p(x_local.data_ptr()),
+                                                               x_local.numel(), 1, fpe, int(early_exit), _args(torch),
+                                                               C.c_void_p(out.data_ptr()), _evh(ev_start), _evh(ev_end)),
+           "exsum_allreduce_pipelined_dev")
+    return out
+
+
+def exdot_allreduce_pipelined(comm, x_local, y_local, fpe=8, early_exit=True, out=None, ev_start=None, ev_end=None):
+    from . import load_library, _check, _require_gpu, new_record_buffer
+    torch = _require_gpu()
+    if out is None:
+        out = new_record_buffer()
+    _check(load_library().exblas_exdot_allreduce_pipelined_dev(comm.handle, C.c_void_p(x_local.data_ptr()), 1,
+                                                               C.c_void_p(y_local.data_ptr()), 1, x_local.numel(), fpe,
+                                                               int(early_exit), _args(torch), C.c_void_p(out.data_ptr()),
+                                                               _evh(ev_start), _evh(ev_end)),
+           "exdot_allreduce_pipelined_dev")
+    return out
+
+
+def pipeline_drain(comm):
+    """The current stream waits for the pipelined second halves in flight; slot 0 selected again."""
+    from . import load_library, _check, _require_gpu
+    torch = _require_gpu()
+    _check(load_library().exblas_pipeline_drain_dev(comm.handle, _args(torch)), "pipeline_drain_dev")
+
+
 def allreduce_finish(comm, out=None):
     """Second half of the calls above on the current stream: normalise the selected accumulator slot, all-reduce the
     digit set, carry-propagate + round (see ``exblas_allreduce_finish_dev``)."""

@@ -280,6 +280,22 @@ int exblas_exdot_allreduce_dev(exblas_comm_t *comm, const double *d_a_local, int
  * carry-propagate + round.  A caller that pipelines reductions runs this on a second stream while the next streaming
  * kernel fills the other slot (bench.py). */
 int exblas_allreduce_finish_dev(exblas_comm_t *comm, void *stream, int64_t *d_out);
+/* Throughput form for a caller that runs reduction after reduction (bench.py's step loop): ONE call per reduction.  The
+ * streaming kernel runs on `stream` into the accumulator slot the communicator alternates (0, 1, 0, ...); the second half
+ * -- normalise, all-reduce, carry-propagate + round into d_out -- is enqueued on the communicator's own side stream behind
+ * an event, so it overlaps the NEXT call's streaming kernel (a slot is reused only after its second half has left it
+ * zero: the call makes `stream` wait for that).  d_out of call i is complete once work ordered after
+ * exblas_pipeline_drain_dev(comm, stream) runs (which also re-selects slot 0); use distinct d_out buffers for reductions
+ * in flight (two).  ev_kernel_start / ev_kernel_end: optional hipEvent_t recorded on `stream` around the streaming kernel
+ * (bench.py times the kernel with them), NULL otherwise.  Uses the device's default context: do not interleave with
+ * exblas_*_accumulate_dev / exblas_finish_dev on it before draining. */
+int exblas_exsum_allreduce_pipelined_dev(exblas_comm_t *comm, const double *d_a_local, int64_t n_local, int64_t inca,
+                                         int fpe, int early_exit, void *stream, int64_t *d_out, void *ev_kernel_start,
+                                         void *ev_kernel_end);
+int exblas_exdot_allreduce_pipelined_dev(exblas_comm_t *comm, const double *d_a_local, int64_t inca,
+                                         const double *d_b_local, int64_t incb, int64_t n_local, int fpe, int early_exit,
+                                         void *stream, int64_t *d_out, void *ev_kernel_start, void *ev_kernel_end);
+int exblas_pipeline_drain_dev(exblas_comm_t *comm, void *stream);
 /* Row-sharded ExGEMV.  transa 'N': rank r owns rows [first, last) = exblas_shard_range(m, r, size) of A and y;
  * d_a_local is that row block (column-major, leading dimension lda >= last - first).  transa 'T': rank r owns the
  * OUTPUTS [first, last) of n, i.e. columns first..last-1 of A; d_a_local points at column `first`.  d_x is the full
