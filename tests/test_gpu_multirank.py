@@ -205,6 +205,30 @@ def test_rccl_transport_one_rank():
         ex.exgemm_sharded(comm, m, n, k, 1.0, A, B, 1.0, got_c, fpe, ee)
         torch.cuda.synchronize()
         assert torch.equal(want_c.view(torch.int64), got_c.view(torch.int64)), (fpe, ee)
+    # pipelined form: one call per reduction, the second half on the communicator's side stream; seven reductions in
+    # flight two at a time (slots alternate, each reused three times), every record equal to the plain call's
+    vecs = [ex.gen_dev("ill_cond", (1 << 20) + 17 * i, 30 + i, 1e32) for i in range(7)]
+    ws = [ex.gen_dev("lognormal", (1 << 20) + 17 * i, 40 + i, 0.0, 2.0) for i in range(7)]
+    want_s = [ex.read_record(ex.exsum_dev(v, 8, True)) for v in vecs]
+    want_d = [ex.read_record(ex.exdot_dev(v, w, 6, True)) for v, w in zip(vecs, ws)]
+    recs_s = [ex.new_record_buffer() for _ in vecs]
+    recs_d = [ex.new_record_buffer() for _ in vecs]
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0.record()
+    t1.record()
+    for i, v in enumerate(vecs):
+        ex.exsum_allreduce_pipelined(comm, v, 8, True, out=recs_s[i], ev_start=t0 if i == 3 else None,
+                                     ev_end=t1 if i == 3 else None)
+    for i, (v, w) in enumerate(zip(vecs, ws)):
+        ex.exdot_allreduce_pipelined(comm, v, w, 6, True, out=recs_d[i])
+    ex.pipeline_drain(comm)
+    torch.cuda.synchronize()
+    assert t0.elapsed_time(t1) > 0.0
+    for i in range(len(vecs)):
+        for got, want in ((ex.read_record(recs_s[i]), want_s[i]), (ex.read_record(recs_d[i]), want_d[i])):
+            assert got.exact == want.exact and got.refmode == want.refmode and (got.canon == want.canon).all(), i
+    again = ex.read_record(ex.exsum_dev(vecs[0], 8, True))       # slot 0 is selected again, accumulators are zero
+    assert again.exact == want_s[0].exact and (again.canon == want_s[0].canon).all()
     # graph capture of exsum + all-reduce + finalize
     x = ex.gen_dev("ill_cond", 1 << 20, 3, 1e32)
     rec = ex.new_record_buffer()
