@@ -204,6 +204,7 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_exdot(const double *__restrict__
     long long *col = s_acc + wave * NL * COPIES + (lane & (COPIES - 1));
     unsigned flags = 0;
     LdsSink<COPIES> sink{col, flags};
+    long long *const lo_acc = low_acc_of(gflags);   // exact home of products below 2^-968 (prod_underflow_divert)
     double fpe[N > 0 ? N : 1];
 #pragma unroll
     for (int i = 0; i < (N > 0 ? N : 1); ++i) fpe[i] = 0.0;
@@ -229,8 +230,9 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_exdot(const double *__restrict__
                 x[2 * u] = two_prod(ra[u].x, rb[u].x, e[2 * u]);
                 x[2 * u + 1] = two_prod(ra[u].y, rb[u].y, e[2 * u + 1]);
             }
-            prod_underflow_note<2 * U>(x, flags, [&](int j) { return (j & 1 ? ra[j >> 1].y : ra[j >> 1].x) != 0.0 && (j & 1 ? rb[j >> 1].y : rb[j >> 1].x) != 0.0; });
-            fpe_absorb_prod_adaptive<N, EE, 2 * U>(fpe, x, e, sink, bypass);
+            if (!prod_underflow_divert<2 * U>(x, e, sink, lo_acc, [&](int j) { return j & 1 ? ra[j >> 1].y : ra[j >> 1].x; },
+                                              [&](int j) { return j & 1 ? rb[j >> 1].y : rb[j >> 1].x; }))
+                fpe_absorb_prod_adaptive<N, EE, 2 * U>(fpe, x, e, sink, bypass);
         }
     } else {
         long long t = blockIdx.x;
@@ -257,7 +259,9 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_exdot(const double *__restrict__
                         x[2 * u] = two_prod(ra[h * H + u].x, rb[h * H + u].x, e[2 * u]);
                         x[2 * u + 1] = two_prod(ra[h * H + u].y, rb[h * H + u].y, e[2 * u + 1]);
                     }
-                    prod_underflow_note<2 * H>(x, flags, [&](int j) { return (j & 1 ? ra[h * H + (j >> 1)].y : ra[h * H + (j >> 1)].x) != 0.0 && (j & 1 ? rb[h * H + (j >> 1)].y : rb[h * H + (j >> 1)].x) != 0.0; });
+                    const bool diverted = prod_underflow_divert<2 * H>(
+                        x, e, sink, lo_acc, [&](int j) { return j & 1 ? ra[h * H + (j >> 1)].y : ra[h * H + (j >> 1)].x; },
+                        [&](int j) { return j & 1 ? rb[h * H + (j >> 1)].y : rb[h * H + (j >> 1)].x; });
                     if (tn < ntiles) {
                         const long long base = tn * TILE + threadIdx.x;
 #pragma unroll
@@ -266,7 +270,7 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_exdot(const double *__restrict__
                             rb[h * H + u] = ld2<NT>(vb + base + (h * H + u) * BLOCK);
                         }
                     }
-                    fpe_absorb_prod_adaptive<N, EE, 2 * H>(fpe, x, e, sink, bypass);
+                    if (!diverted) fpe_absorb_prod_adaptive<N, EE, 2 * H>(fpe, x, e, sink, bypass);
                 }
                 t = tn;
             }
@@ -290,8 +294,9 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_exdot(const double *__restrict__
                     x[2 * u] = two_prod(pa[u].x, pb[u].x, e[2 * u]);
                     x[2 * u + 1] = two_prod(pa[u].y, pb[u].y, e[2 * u + 1]);
                 }
-                prod_underflow_note<2 * U>(x, flags, [&](int j) { return (j & 1 ? pa[j >> 1].y : pa[j >> 1].x) != 0.0 && (j & 1 ? pb[j >> 1].y : pb[j >> 1].x) != 0.0; });
-                fpe_absorb_prod_adaptive<N, EE, 2 * U, LdsSink<COPIES>, ZM>(fpe, x, e, sink, bypass);
+                if (!prod_underflow_divert<2 * U>(x, e, sink, lo_acc, [&](int j) { return j & 1 ? pa[j >> 1].y : pa[j >> 1].x; },
+                                                  [&](int j) { return j & 1 ? pb[j >> 1].y : pb[j >> 1].x; }))
+                    fpe_absorb_prod_adaptive<N, EE, 2 * U, LdsSink<COPIES>, ZM>(fpe, x, e, sink, bypass);
             };
             for (;;) {
                 fill(t + gridDim.x, rc, rd);
@@ -311,15 +316,15 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_exdot(const double *__restrict__
         double x[2], e[2];
         x[0] = two_prod(ra.x, rb.x, e[0]);
         x[1] = two_prod(ra.y, rb.y, e[1]);
-        prod_underflow_note<2>(x, flags, [&](int j) { return (j ? ra.y : ra.x) != 0.0 && (j ? rb.y : rb.x) != 0.0; });
-        fpe_absorb_prod<N, false, 2>(fpe, x, e, sink);
+        if (!prod_underflow_divert<2>(x, e, sink, lo_acc, [&](int j) { return j ? ra.y : ra.x; }, [&](int j) { return j ? rb.y : rb.x; }))
+            fpe_absorb_prod<N, false, 2>(fpe, x, e, sink);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0 && (n & 1)) {
-        double e, p = two_prod_safe(a[n - 1], b[n - 1], e);
-        if (expo_field(p) < LOW_EXPO && a[n - 1] != 0.0 && b[n - 1] != 0.0) flags |= FLAG_PUNDER;
-        if (__builtin_isinf(p) && __builtin_isfinite(a[n - 1]) && __builtin_isfinite(b[n - 1])) flags |= FLAG_POVER;
-        lds_add<COPIES>(col, p, flags);
-        lds_add<COPIES>(col, e, flags);  // e == 0 when p overflowed (two_prod_safe)
+        double x1[1], e1[1];
+        x1[0] = two_prod(a[n - 1], b[n - 1], e1[0]);
+        // (only this lane is active: the helper's votes are votes of one)
+        if (!prod_underflow_divert<1>(x1, e1, sink, lo_acc, [&](int) { return a[n - 1]; }, [&](int) { return b[n - 1]; }))
+            sink_product(sink, x1[0], e1[0]);
     }
     fpe_flush<N, COPIES>(fpe, col, flags);
     block_epilogue<COPIES>(s_acc, flags, gacc, gflags, ngroups);
@@ -338,6 +343,7 @@ __global__ void __launch_bounds__(BLOCK) k_exdot_strided(const double *__restric
     long long *col = s_acc + wave * NL * COPIES + (lane & (COPIES - 1));
     unsigned flags = 0;
     LdsSink<COPIES> sink{col, flags};
+    long long *const lo_acc = low_acc_of(gflags);
     double fpe[N > 0 ? N : 1];
 #pragma unroll
     for (int i = 0; i < (N > 0 ? N : 1); ++i) fpe[i] = 0.0;
@@ -352,8 +358,8 @@ __global__ void __launch_bounds__(BLOCK) k_exdot_strided(const double *__restric
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) x[u] = two_prod(va[u], vb[u], e[u]);
-        prod_underflow_note<4>(x, flags, [&](int j) { return va[j] != 0.0 && vb[j] != 0.0; });
-        fpe_absorb_prod<N, false, 4>(fpe, x, e, sink);
+        if (!prod_underflow_divert<4>(x, e, sink, lo_acc, [&](int j) { return va[j]; }, [&](int j) { return vb[j]; }))
+            fpe_absorb_prod<N, false, 4>(fpe, x, e, sink);
     }
     fpe_flush<N, COPIES>(fpe, col, flags);
     block_epilogue<COPIES>(s_acc, flags, gacc, gflags, ngroups);
@@ -410,13 +416,48 @@ __global__ void __launch_bounds__(64) k_finalize(long long *sets, int nsets, int
     long long in0 = __shfl_up(hi0, 1), in1 = __shfl_up(hi1, 1);
     const long long h63 = __shfl(hi0, 63);
     if (lane == 0) { in0 = 0; in1 = h63; }
-    const long long v0 = lo0 + in0, v1 = (lane < NL - 64) ? lo1 + in1 : 0;
+    long long v0 = lo0 + in0, v1 = (lane < NL - 64) ? lo1 + in1 : 0;
     if (zero_sets) {
         for (int i = lane; i < nsets * set_stride; i += 64) sets[i] = 0;
         if (lane == 0 && gflags) *gflags = 0;
     }
+    // ExDOT with products below 2^-968 (FLAG_PUNDER): fold the LOW accumulator in.  Its digits at or above 2^-1074 are
+    // added to the main digits exactly; what lies below becomes the half / sticky bits of the rounding.  Rare, so one
+    // lane does it with the scalar routines (two carry passes over 68 digits + one rounding).
+    __shared__ long long s_v[NL], s_lo[NL];
+    __shared__ unsigned long long s_ex;
+    bool low_folded = false;
+    if (gflags && (flags & FLAG_PUNDER)) {   // wave-uniform
+        long long *lo = low_acc_of(gflags);
+        s_lo[lane] = lo[lane];
+        s_v[lane] = v0;
+        if (lane < NL - 64) {
+            s_lo[64 + lane] = lo[64 + lane];
+            s_v[64 + lane] = v1;
+        }
+        if (zero_sets) {
+            lo[lane] = 0;
+            if (lane < NL - 64) lo[64 + lane] = 0;
+        }
+        __syncthreads();
+        if (lane == 0) {
+            normalize_digits(s_lo);
+            for (int j = LOW_SHIFT_DIGITS; j < NL; ++j) s_v[j - LOW_SHIFT_DIGITS] += s_lo[j];
+            normalize_digits(s_v);
+            const bool half = (s_lo[LOW_SHIFT_DIGITS - 1] >> 31) & 1ll;
+            bool sticky = (s_lo[LOW_SHIFT_DIGITS - 1] & 0x7fffffffll) != 0;
+            for (int j = 0; j < LOW_SHIFT_DIGITS - 1; ++j) sticky = sticky || s_lo[j] != 0;
+            s_ex = round_exact_bits_frac(s_v, half, sticky);
+        }
+        __syncthreads();
+        v0 = s_v[lane];
+        v1 = lane < NL - 64 ? s_v[64 + lane] : 0;
+        flags |= FLAG_PLOW_EXACT;
+        low_folded = true;
+    }
     // every input word has been read (into registers) before the first output word is written: out may alias sets
-    const WaveFinish r = finish_wave(v0, v1, flags);
+    WaveFinish r = finish_wave(v0, v1, flags);
+    if (low_folded && !(flags & FLAG_NONFINITE)) r.ex = s_ex;
     write_record_wave(r, flags, out);
 }
 

@@ -105,8 +105,9 @@ static void init_ctx(Ctx &c, int device, int layer)
     EXB_CHECK(crt_tables_upload());
     EXB_CHECK(hipMalloc(&c.gacc_all, 2 * sizeof(long long) * NL * c.ngroups));
     EXB_CHECK(hipMemset(c.gacc_all, 0, 2 * sizeof(long long) * NL * c.ngroups));
-    EXB_CHECK(hipMalloc(&c.gflags_all, 128));
-    EXB_CHECK(hipMemset(c.gflags_all, 0, 128));
+    // per slot: the flag word (own 64-byte line) + the low accumulator of ExDOT (superacc.hip.h: low_acc_of)
+    EXB_CHECK(hipMalloc(&c.gflags_all, 2 * FLAG_BLOCK_BYTES));
+    EXB_CHECK(hipMemset(c.gflags_all, 0, 2 * FLAG_BLOCK_BYTES));
     c.gacc = c.gacc_all;
     c.gflags = c.gflags_all;
     c.slot = 0;
@@ -371,7 +372,7 @@ int exblas_set_accumulator_slot(int slot)
     if (slot < 0 || slot > 1) return (int)hipErrorInvalidValue;
     c.slot = slot;
     c.gacc = c.gacc_all + (size_t)slot * NL * c.ngroups;
-    c.gflags = c.gflags_all + 16 * slot;
+    c.gflags = (unsigned *)((char *)c.gflags_all + (size_t)FLAG_BLOCK_BYTES * slot);
     return 0;
 }
 

@@ -26,22 +26,6 @@ constexpr unsigned BIG_EXPO = 1023u + 1000u;
 // TwoProd error term is then not representable
 constexpr unsigned LOW_EXPO = 1023u - 968u;
 
-// ExDOT: flag products of two non-zero operands whose low bits the accumulator cannot hold (FLAG_PUNDER, superacc.hip.h).
-// One exponent minimum + one wave-uniform vote per tile on the hot path; the per-element test (which needs the operands:
-// a product that underflowed to zero looks like 0 * x) only runs in tiles that hold a tiny or zero product.
-template <int CNT, class F>
-__device__ __forceinline__ void prod_underflow_note(const double (&p)[CNT], unsigned &flags, F &&both_nonzero)
-{
-    unsigned mn = 0x7ffu;
-#pragma unroll
-    for (int j = 0; j < CNT; ++j) mn = min(mn, expo_field(p[j]));
-    if (__builtin_expect(__any(mn < LOW_EXPO), 0)) {
-#pragma unroll
-        for (int j = 0; j < CNT; ++j)
-            if (expo_field(p[j]) < LOW_EXPO && both_nonzero(j)) flags |= FLAG_PUNDER;
-    }
-}
-
 // "is any of these doubles non-zero" with 32-bit integer ops only (two per element instead of an fp64
 // compare each): OR of the low words and the high words shifted left by one (drops the sign, so -0.0 is zero)
 template <int CNT, int ZM = 0>
@@ -109,6 +93,45 @@ __device__ __forceinline__ void sink_product(Sink &sink, double p, double e)
     } else if (__builtin_isinf(p) && __builtin_isinf(e)) {
         sink.note(FLAG_POVER);
     }
+}
+
+// ExDOT: products of two non-zero operands below 2^-968 have bits below 2^-1074 that the accumulator cannot hold (their
+// TwoProd error term is not representable).  One exponent minimum + one wave-uniform vote per tile on the hot path; only
+// tiles that hold a tiny or zero product look at the operands (a product that underflowed to zero looks like 0 * x).
+// A tile with such a product is DIVERTED as a whole (returns true: the caller skips the expansion for it): every ordinary
+// product of the tile goes straight to the integer accumulator (exact), every tiny one is formed again at a scaled
+// exponent -- a 2^-ea (in [1/2, 1)) times b 2^(LOW_SHIFT_BITS + ea): both factors and the product are normal, so
+// TwoProd is error-free -- and added, exactly, to the LOW accumulator `lo` (global memory, the geometry of the main one,
+// unit 2^-(1074 + LOW_SHIFT_BITS)); the finalize kernel folds it back (superacc.hip.h: FLAG_PLOW_EXACT).
+template <int CNT, class Sink, class FA, class FB>
+__device__ __forceinline__ bool prod_underflow_divert(const double (&p)[CNT], const double (&e)[CNT], Sink &sink,
+                                                      long long *lo, FA &&a_of, FB &&b_of)
+{
+    unsigned mn = 0x7ffu;
+#pragma unroll
+    for (int j = 0; j < CNT; ++j) mn = min(mn, expo_field(p[j]));
+    if (__builtin_expect(!__any(mn < LOW_EXPO), 1)) return false;
+    bool hz = false;
+#pragma unroll
+    for (int j = 0; j < CNT; ++j) hz |= expo_field(p[j]) < LOW_EXPO && a_of(j) != 0.0 && b_of(j) != 0.0;
+    if (!__any(hz)) return false;   // zeros only
+    GlobalSink low{lo};
+#pragma unroll   // (unrolled although cold: a rolled loop would index the callers' register arrays dynamically = scratch memory)
+    for (int j = 0; j < CNT; ++j) {
+        const double a = a_of(j), b = b_of(j);
+        if (expo_field(p[j]) < LOW_EXPO && a != 0.0 && b != 0.0) {
+            int ea;
+            const double a1 = frexp(a, &ea);                       // a = a1 2^ea, 1/2 <= |a1| < 1 (subnormal a included)
+            const double b1 = ldexp(b, LOW_SHIFT_BITS + ea);       // normal: a b 2^LOW_SHIFT_BITS lies in [2^-932, 2^249)
+            const double P = a1 * b1, E = __builtin_fma(a1, b1, -P);
+            low.add(P);
+            if (E != 0.0) low.add(E);
+        } else {
+            sink_product(sink, p[j], e[j]);
+        }
+    }
+    sink.note(FLAG_PUNDER);
+    return true;
 }
 
 // ---- the cascade -----------------------------------------------------------------------------

@@ -45,6 +45,15 @@ constexpr unsigned FLAG_PINF = 1u, FLAG_NINF = 2u, FLAG_NAN = 4u;
 // products truncated at 2^-1074); POVER = a product of two FINITE operands overflowed to +-Inf (the result is +-Inf / NaN
 // as in IEEE arithmetic although the exact sum may be finite).
 constexpr unsigned FLAG_PUNDER = 8u, FLAG_POVER = 16u, FLAG_NONFINITE = 7u;
+// PLOW_EXACT (set by the finalize kernel of a single-device reduction, together with PUNDER): the products flagged by
+// PUNDER did NOT lose anything -- each was formed exactly at a scaled exponent and accumulated in the LOW accumulator
+// (same 68-limb geometry, unit 2^-(1074 + LOW_SHIFT_BITS)), which the finalize folded back: its part at or above 2^-1074
+// exactly, the rest as the half / sticky bits of the rounding.  The result is then the correctly rounded exact dot product.
+constexpr unsigned FLAG_PLOW_EXACT = 32u;
+constexpr int LOW_SHIFT_DIGITS = 38, LOW_SHIFT_BITS = 32 * LOW_SHIFT_DIGITS;   // 1216: a b 2^1216 is normal for every a b >= 2^-2148
+// per accumulator slot: one 64-byte line for the flag word, then the low accumulator (SET_WORDS int64: 68 limbs + pad)
+constexpr int FLAG_BLOCK_BYTES = 64 + 72 * 8;
+__device__ __forceinline__ long long *low_acc_of(unsigned *gflags) { return (long long *)((char *)gflags + 64); }
 
 // ---------------------------------------------------------------------------------------------
 // error-free transforms (ExSUM.FPE.cl:27-32 KnuthTwoSum; ExDOT.Superacc.cl:25-29 TwoProductFMA)
@@ -163,6 +172,51 @@ __device__ inline unsigned long long round_exact_bits(const long long *v)
     const bool rnd = (w >> 10) & 1ull;
     if (rnd && (sticky || (bits & 1ull))) bits += 1;       // carries into the exponent naturally
     if ((bits >> 52) >= 0x7ffull) bits = 0x7ff0000000000000ull;  // overflow -> inf
+    return sign | bits;
+}
+
+// The same for value = (normalised digits) + f units, 0 <= f < 1, f known by its first bit (half) and whether anything
+// follows it (sticky): the sub-LSB part of a reduction whose low accumulator held something (PLOW_EXACT).
+__device__ inline unsigned long long round_exact_bits_frac(const long long *v, bool half, bool sticky)
+{
+    if (!half && !sticky) return round_exact_bits(v);
+    const bool neg = v[NL - 1] < 0;
+    unsigned mag[NL];
+    if (!neg) {
+        for (int i = 0; i < NL; ++i) mag[i] = (unsigned)v[i];
+    } else {
+        // |H + f| = (|H| - 1) + (1 - f): magnitude digits |H| - 1 = ~H (no +1), fraction 1 - f
+        for (int i = 0; i < NL; ++i) mag[i] = ~(unsigned)v[i];
+        const bool h = half, st = sticky;
+        half = !(h && st);      // 1 - f >= 1/2  <=>  f <= 1/2
+        sticky = !(h && !st);   // 1 - f != 1/2 exactly (and it is never 0)
+    }
+    const unsigned long long sign = neg ? 0x8000000000000000ull : 0ull;
+    int t = NL - 1;
+    while (t >= 0 && mag[t] == 0) --t;
+    const int lz = t >= 0 ? __builtin_clz(mag[t]) : 0;
+    const int msb = t >= 0 ? 32 * t + 31 - lz : -1;
+    if (msb <= 52) {
+        // spacing of the doubles here is one unit (2^-1074): round at the unit position
+        unsigned long long val = t < 0 ? 0ull : (((unsigned long long)(t >= 1 ? mag[1] : 0u) << 32) | mag[0]);
+        if (half && (sticky || (val & 1ull))) val += 1;   // 2^53 units: the bit pattern carries into the exponent naturally
+        return sign | val;
+    }
+    const unsigned d1 = (t >= 1) ? mag[t - 1] : 0u, d2 = (t >= 2) ? mag[t - 2] : 0u;
+    unsigned long long w = ((unsigned long long)mag[t] << 32) | d1;
+    unsigned rest;
+    if (lz) {
+        w = (w << lz) | (unsigned long long)(d2 >> (32 - lz));
+        rest = d2 << lz;
+    } else {
+        rest = d2;
+    }
+    bool st2 = true;   // the fraction is non-zero: everything below the rounding position is sticky
+    (void)rest;
+    unsigned long long bits = ((unsigned long long)(msb - 52) << 52) + (w >> 11);
+    const bool rnd = (w >> 10) & 1ull;
+    if (rnd && (st2 || (bits & 1ull))) bits += 1;
+    if ((bits >> 52) >= 0x7ffull) bits = 0x7ff0000000000000ull;
     return sign | bits;
 }
 

@@ -52,14 +52,23 @@ extern "C" {
 #define EXBLAS_OUT_WORDS 128
 #define EXBLAS_OUT_EXACT 0    /* bit pattern of the correctly rounded double */
 #define EXBLAS_OUT_REFMODE 1  /* bit pattern of the reference-compatible rounding */
-#define EXBLAS_OUT_FLAGS 2    /* bit0 +inf, bit1 -inf, bit2 NaN seen in the input; ExDOT also: bit3 = a product of two
-                               * non-zero operands was below 2^-968, so bits of it below 2^-1074 were dropped (the result is
-                               * the correctly rounded sum of the products truncated there); bit4 = a product of two FINITE
-                               * operands overflowed (the result is +-Inf / NaN as in IEEE arithmetic).  No bit set = the
-                               * result is the correctly rounded EXACT dot product (the MPFR-4196 value of
-                               * tests/test.exdot.gpu.cpp:24-46).  The reference's kernels have the same two limits, silently. */
+#define EXBLAS_OUT_FLAGS 2    /* bit0 +inf, bit1 -inf, bit2 NaN seen in the input.  ExDOT also:
+                               * bit3 (PRODUCT_UNDERFLOW) = a product of two non-zero operands was below 2^-968, i.e. had bits
+                               *   below 2^-1074, the last place of the double-range accumulator;
+                               * bit5 (PRODUCT_LOW_EXACT), set with bit3 by a single-device reduction = those products lost
+                               *   nothing: each was formed again at a scaled exponent (error-free) and summed in a second,
+                               *   LOW accumulator that the finalize kernel folded back (its part below 2^-1074 as the half /
+                               *   sticky bits of the rounding) -- the result is the correctly rounded EXACT dot product.  With
+                               *   bit3 alone (a multi-rank result: the 576-byte digit set carries the main digits, not a
+                               *   rank's sub-2^-1074 remainder) it is the correctly rounded sum of the ranks' values truncated
+                               *   at 2^-1074;
+                               * bit4 (PRODUCT_OVERFLOW) = a product of two FINITE operands overflowed: the result is +-Inf / NaN
+                               *   as in IEEE arithmetic although the exact sum may be finite.
+                               * No bit, or bits 3 + 5: the result is the MPFR-4196 value of tests/test.exdot.gpu.cpp:24-46.
+                               * The reference's kernels have both limits, silently. */
 #define EXBLAS_FLAG_PRODUCT_UNDERFLOW 8
 #define EXBLAS_FLAG_PRODUCT_OVERFLOW 16
+#define EXBLAS_FLAG_PRODUCT_LOW_EXACT 32
 #define EXBLAS_OUT_CANON 4    /* 41 canonical limbs (52-bit, reference geometry) */
 #define EXBLAS_OUT_DIGITS 48  /* 68 normalised 32-bit digits, then 3 flag indicators + 1 pad word: */
 #define EXBLAS_SET_WORDS 72   /* words [48,120) = one "digit set", the int64-sum all-reduce payload */

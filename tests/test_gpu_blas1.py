@@ -387,58 +387,57 @@ def test_blas1_randomized_soak(ex):
     assert r.returncode == 0 and "0 mismatches" in r.stdout, (r.stdout[-3000:], r.stderr[-2000:])
 
 
-FLAG_PUNDER, FLAG_POVER = 8, 16
+FLAG_PUNDER, FLAG_POVER, FLAG_PLOW_EXACT = 8, 16, 32
 
 
-def test_exdot_product_domain_is_fenced(ex, oracle):
-    """The double-range accumulator holds a 106-bit product only while it neither overflows nor reaches below 2^-1074 --
-    the limit the reference's kernels share (its test oracle sums exact products in 4196 bits for that reason,
-    tests/test.exdot.gpu.cpp:24-46).  Outside that domain the record says so (EXBLAS_OUT_FLAGS bit 3 / bit 4); inside it
-    -- no flag -- the result IS the MPFR-4196 value.  Families: products straddling 2^-968 (the first exponent whose
-    TwoProd error term can fall below 2^-1074), products that underflow to zero, finite operands whose product
-    overflows, and zeros (0 * x must not raise the flag).  Every variant, vector / strided / odd-tail code paths."""
+def test_exdot_product_domain(ex, oracle):
+    """A 106-bit product fits the double-range accumulator only while it neither overflows nor reaches below 2^-1074 -- the
+    limit of the reference's kernels (its test oracle sums exact products in 4196 bits for that reason,
+    tests/test.exdot.gpu.cpp:24-46).  Here the LOW side is closed: products below 2^-968 are formed again at a scaled
+    exponent (error-free) and accumulated in a second accumulator that the finalize folds back, so the result is the
+    MPFR-4196 value; the record says so (EXBLAS_OUT_FLAGS bit 3 + bit 5).  The HIGH side is fenced: a product of two
+    finite operands that overflows sets bit 4 and the result is +-Inf / NaN as IEEE arithmetic gives.  No bit set = the
+    exact domain of round 2: limbs equal to the oracle's, result == MPFR.  Families: products straddling 2^-968, products
+    that underflow to zero, zeros (0 * x must not raise anything), overflow; every variant; vector / strided / odd-tail."""
     import torch
     rng = np.random.default_rng(11)
     mp = oracle.mpfr()
+    assert mp is not None, "this test needs the MPFR oracle (oracle/libmpfr_oracle.so)"
 
     def run(a, b, fpe, ee, inca=1):
+        nn = (a.size + inca - 1) // inca
         rec = ex.read_record(ex.exdot_dev(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), fpe, ee, incx=inca,
-                                          incy=inca, n=(a.size + inca - 1) // inca))
-        # the oracle restates the same arithmetic (fma error terms rounded where they underflow): limbs stay equal
-        r, limbs = oracle.exdot(a, b, fpe, ee, inca=inca, incb=inca, limbs=True)
-        assert (rec.canon == limbs).all() and same_double(rec.exact, r)
+                                          incy=inca, n=nn))
+        want = oracle.mpfr_exdot(a, b, inca=inca, incb=inca, n=nn)
+        assert same_double(rec.exact, want), (fpe, ee, rec.flags, rec.exact, want)
+        if rec.flags == 0:     # inside the exact domain the oracle restates the same arithmetic: limbs equal
+            r, limbs = oracle.exdot(a, b, fpe, ee, inca=inca, incb=inca, limbs=True)
+            assert (rec.canon == limbs).all() and same_double(rec.exact, r)
         return rec
 
     n = 20000 + 3                                     # odd: the scalar tail runs too
     mant = lambda k: rng.uniform(1.0, 2.0, k) * rng.choice([-1.0, 1.0], k)  # noqa: E731
     big = np.ldexp(mant(n), rng.integers(-20, 20, n))
     for fpe, ee in FPE_VARIANTS_DOT:
-        # (1) safely inside: every product at or above 2^-960 -> no flag, equal to MPFR-4196
+        # (1) safely inside: every product at or above 2^-960 -> no flag
         a = np.ldexp(mant(n), rng.integers(-480, -450, n))
         b = np.ldexp(mant(n), rng.integers(-480, -440, n))
-        rec = run(a, b, fpe, ee)
-        assert rec.flags == 0
-        if mp is not None:
-            assert same_double(rec.exact, oracle.mpfr_exdot(a, b)), (fpe, ee)
-        # (2) ONE product below 2^-968 among ordinary ones -> bit 3, result finite
+        assert run(a, b, fpe, ee).flags == 0
+        # (2) ONE product below 2^-968 among ordinary ones
         a2, b2 = big.copy(), big[::-1].copy()
         j = int(rng.integers(0, n))
         a2[j], b2[j] = np.ldexp(1.5, -500), np.ldexp(1.25, -480)          # 2^-980: error term below 2^-1074
-        rec = run(a2, b2, fpe, ee)
-        assert rec.flags == FLAG_PUNDER and np.isfinite(rec.exact), (fpe, ee, rec.flags)
+        assert run(a2, b2, fpe, ee).flags == FLAG_PUNDER | FLAG_PLOW_EXACT
         # (3) a product that underflows to zero entirely
         a2[j], b2[j] = np.ldexp(1.0, -600), np.ldexp(1.0, -600)
-        assert run(a2, b2, fpe, ee).flags == FLAG_PUNDER
+        assert run(a2, b2, fpe, ee).flags == FLAG_PUNDER | FLAG_PLOW_EXACT
         # (4) zeros are not underflow: 0 * x, x * 0, 0 * 0, subnormal * 0
         a3, b3 = big.copy(), big[::-1].copy()
         a3[::7] = 0.0
         b3[::5] = 0.0
         a3[3], b3[3] = 5e-324, 0.0
-        rec = run(a3, b3, fpe, ee)
-        assert rec.flags == 0
-        if mp is not None:
-            assert same_double(rec.exact, oracle.mpfr_exdot(a3, b3)), (fpe, ee)
-        # (5) finite operands, overflowing product -> bit 4 and +Inf / -Inf / NaN as IEEE arithmetic gives
+        assert run(a3, b3, fpe, ee).flags == 0
+        # (5) finite operands, overflowing product -> bit 4 and +Inf / -Inf as IEEE arithmetic gives
         a4, b4 = big.copy(), big[::-1].copy()
         a4[j], b4[j] = np.ldexp(1.0, 600), np.ldexp(1.0, 500)
         rec = ex.read_record(ex.exdot_dev(torch.from_numpy(a4).cuda(), torch.from_numpy(b4).cuda(), fpe, ee))
@@ -455,23 +454,75 @@ def test_exdot_product_domain_is_fenced(ex, oracle):
     b = np.zeros(64)
     a[0], b[0] = np.ldexp(1.0 + 2.0 ** -52, -484), np.ldexp(1.0 + 2.0 ** -52, -484)   # product 2^-968 (1 + 2^-51 + 2^-104)
     a[2], b[2] = 3.0, 5.0
-    rec = run(a, b, 8, True, inca=2)
-    assert rec.flags == 0
-    if mp is not None:
-        assert same_double(rec.exact, oracle.mpfr_exdot(a, b, inca=2, incb=2, n=32))
-    a[0] = np.ldexp(1.0 + 2.0 ** -52, -485)                                            # one binade lower: flagged
-    assert run(a, b, 8, True, inca=2).flags == FLAG_PUNDER
+    assert run(a, b, 8, True, inca=2).flags == 0
+    a[0] = np.ldexp(1.0 + 2.0 ** -52, -485)                                            # one binade lower
+    assert run(a, b, 8, True, inca=2).flags == FLAG_PUNDER | FLAG_PLOW_EXACT
+
+
+def test_exdot_underflowing_products_are_summed_exactly(ex, oracle):
+    """The low accumulator at work: MANY products below 2^-968 whose sub-2^-1074 parts add up to whole units and to
+    exact ties, totals that are tiny (subnormal results, where the fraction decides the last bit), negative totals
+    (|H| - 1 + (1 - f)), cancellation that leaves only the low parts, and subnormal operands.  Always the MPFR-4196
+    value, for every variant and on the vector, strided and tail paths."""
+    import torch
+    rng = np.random.default_rng(12)
+    assert oracle.mpfr() is not None
+
+    def check(a, b, what, inca=1):
+        nn = (a.size + inca - 1) // inca
+        want = oracle.mpfr_exdot(a, b, inca=inca, incb=inca, n=nn)
+        for fpe, ee in FPE_VARIANTS_DOT:
+            rec = ex.read_record(ex.exdot_dev(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), fpe, ee, incx=inca,
+                                              incy=inca, n=nn))
+            assert same_double(rec.exact, want), (what, fpe, ee, rec.flags, rec.exact.hex(), float(want).hex())
+            assert rec.flags & FLAG_PLOW_EXACT, (what, rec.flags)
+
+    def ld(m, e):
+        return np.ldexp(np.asarray(m, dtype=np.float64), np.asarray(e))
+
+    # (a) pure tiny sums: results are subnormal or just above; 2^-1075 terms pair up into whole units and ties
+    for n in (1, 2, 3, 4, 5, 1000, 4097, 33333):
+        a = ld(np.ones(n), np.full(n, -537))
+        b = ld(np.ones(n), np.full(n, -538))                   # every product = 2^-1075 = half a unit
+        check(a, b, f"halves n={n}")
+        check(-a, b, f"negative halves n={n}")
+        b2 = b.copy()
+        b2[0] *= 1.5                                           # one product 0.75 unit: breaks the ties
+        check(a, b2, f"halves + 0.75 n={n}")
+    # (b) random tiny products (exponents -2148 .. -960), random signs, mixed with subnormal operands
+    for n, inca in ((5000, 1), (5001, 1), (777, 3), (20011, 2)):
+        m = n * inca
+        ea = rng.integers(-1074, -400, m)
+        eb = np.clip(rng.integers(-1500, -960, m) - ea, -1074, 100)
+        a = ld(rng.uniform(1, 2, m) * rng.choice([-1.0, 1.0], m), ea)
+        b = ld(rng.uniform(1, 2, m), eb)
+        check(a, b, f"random tiny n={n} inc={inca}", inca)
+    # (c) an ordinary-sized sum sitting exactly on a rounding tie, decided by the low parts
+    base = np.array([1.0, 2.0 ** -53]), np.array([1.0, 1.0])           # 1 + 2^-53: a tie between 1 and 1 + 2^-52
+    for sg, e1, e2 in ((1.0, -540, -540), (-1.0, -540, -540), (1.0, -550, -550), (-1.0, -1000, -1000), (1.0, -1074, -1074)):
+        a = np.concatenate([base[0], [sg * 2.0 ** e1]])           # the third product is +-2^(e1 + e2): far below 2^-1074
+        b = np.concatenate([base[1], [2.0 ** e2]])
+        check(a, b, f"tie {sg:+.0f} 2^{e1 + e2}")
+        check(-a, b, f"-(tie {sg:+.0f} 2^{e1 + e2})")
+    # (d) cancellation: big terms cancel exactly, only tiny products remain
+    n = 3000
+    x = ld(rng.uniform(1, 2, n), rng.integers(-10, 10, n))
+    a = np.concatenate([x, -x, ld(rng.uniform(1, 2, 500), np.full(500, -540))])
+    b = np.concatenate([x[::-1], x[::-1], ld(rng.uniform(1, 2, 500) * rng.choice([-1.0, 1.0], 500), rng.integers(-560, -520, 500))])
+    check(a, b, "cancellation")
 
 
 def test_exdot_flags_survive_the_digit_set(ex):
     """The product flags travel with the 576-byte digit set (its pad word), so an all-reduced result carries the OR over
-    the ranks: finalize over the digit sets of two records, one flagged, is flagged."""
+    the ranks.  What does NOT travel is the sub-2^-1074 remainder of a rank's low accumulator (the digit set holds the
+    main digits): a multi-rank result with bit 3 set and bit 5 clear is the correctly rounded sum of the ranks' values
+    truncated at 2^-1074 -- the round-2 fence."""
     import torch
     a = torch.tensor([2.0 ** -500, 1.0], dtype=torch.float64, device="cuda")
     b = torch.tensor([2.0 ** -490, 3.0], dtype=torch.float64, device="cuda")
     r1 = ex.exdot_dev(a, b, 8, True)
     r2 = ex.exdot_dev(b[1:], b[1:], 8, True)
-    assert ex.read_record(r1).flags == FLAG_PUNDER and ex.read_record(r2).flags == 0
+    assert ex.read_record(r1).flags == FLAG_PUNDER | FLAG_PLOW_EXACT and ex.read_record(r2).flags == 0
     sets = torch.stack([r1[ex.OUT_DIGITS:ex.OUT_DIGITS + ex.SET_WORDS], r2[ex.OUT_DIGITS:ex.OUT_DIGITS + ex.SET_WORDS]])
     tot = ex.read_record(ex.finalize_dev(sets.contiguous()))
     assert tot.flags == FLAG_PUNDER
