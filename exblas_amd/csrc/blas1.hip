@@ -369,8 +369,11 @@ __global__ void __launch_bounds__(BLOCK) k_exdot_strided(const double *__restric
 // finalize: sum `nsets` limb vectors, ONE carry propagation, canonical limbs, rounding.
 // zero_sets: the input is the context's group accumulators -> leave them zeroed for the next call.
 // ---------------------------------------------------------------------------------------------
+// low_out (with gflags): EXPORT the context's low accumulator as a normalised digit set instead of folding it (the
+// multi-rank path all-reduces it beside the main digit set); low_in: fold THIS digit set (the all-reduced low sets).
 __global__ void __launch_bounds__(64) k_finalize(long long *sets, int nsets, int set_stride, unsigned *gflags,
-                                                 unsigned flags_or, int zero_sets, long long *out)
+                                                 unsigned flags_or, int zero_sets, long long *out,
+                                                 const long long *low_in, long long *low_out)
 {
     // one wavefront: lane l owns limb l and (l < 4) limb 64+l
     const int lane = threadIdx.x;
@@ -427,33 +430,46 @@ __global__ void __launch_bounds__(64) k_finalize(long long *sets, int nsets, int
     __shared__ long long s_v[NL], s_lo[NL];
     __shared__ unsigned long long s_ex;
     bool low_folded = false;
-    if (gflags && (flags & FLAG_PUNDER)) {   // wave-uniform
-        long long *lo = low_acc_of(gflags);
-        s_lo[lane] = lo[lane];
+    const bool have_low = (flags & FLAG_PUNDER) && (low_in || gflags);   // wave-uniform
+    if (low_out && !have_low) {          // export mode, nothing in the low accumulator: an all-zero set
+        low_out[lane] = 0;
+        if (lane < SET_WORDS - 64) low_out[64 + lane] = 0;
+    }
+    if (have_low) {
+        const long long *src = low_in ? low_in : low_acc_of(gflags);
+        s_lo[lane] = src[lane];
         s_v[lane] = v0;
         if (lane < NL - 64) {
-            s_lo[64 + lane] = lo[64 + lane];
+            s_lo[64 + lane] = src[64 + lane];
             s_v[64 + lane] = v1;
         }
-        if (zero_sets) {
+        if (!low_in && zero_sets) {
+            long long *lo = low_acc_of(gflags);
             lo[lane] = 0;
             if (lane < NL - 64) lo[64 + lane] = 0;
         }
         __syncthreads();
         if (lane == 0) {
             normalize_digits(s_lo);
-            for (int j = LOW_SHIFT_DIGITS; j < NL; ++j) s_v[j - LOW_SHIFT_DIGITS] += s_lo[j];
-            normalize_digits(s_v);
-            const bool half = (s_lo[LOW_SHIFT_DIGITS - 1] >> 31) & 1ll;
-            bool sticky = (s_lo[LOW_SHIFT_DIGITS - 1] & 0x7fffffffll) != 0;
-            for (int j = 0; j < LOW_SHIFT_DIGITS - 1; ++j) sticky = sticky || s_lo[j] != 0;
-            s_ex = round_exact_bits_frac(s_v, half, sticky);
+            if (!low_out) {
+                for (int j = LOW_SHIFT_DIGITS; j < NL; ++j) s_v[j - LOW_SHIFT_DIGITS] += s_lo[j];
+                normalize_digits(s_v);
+                const bool half = (s_lo[LOW_SHIFT_DIGITS - 1] >> 31) & 1ll;
+                bool sticky = (s_lo[LOW_SHIFT_DIGITS - 1] & 0x7fffffffll) != 0;
+                for (int j = 0; j < LOW_SHIFT_DIGITS - 1; ++j) sticky = sticky || s_lo[j] != 0;
+                s_ex = round_exact_bits_frac(s_v, half, sticky);
+            }
         }
         __syncthreads();
-        v0 = s_v[lane];
-        v1 = lane < NL - 64 ? s_v[64 + lane] : 0;
-        flags |= FLAG_PLOW_EXACT;
-        low_folded = true;
+        if (low_out) {   // digits < 2^32 (the top one signed and small): sums over 2^31 ranks cannot overflow
+            low_out[lane] = s_lo[lane];
+            if (lane < SET_WORDS - 64) low_out[64 + lane] = lane < NL - 64 ? s_lo[64 + lane] : 0;
+        } else {
+            v0 = s_v[lane];
+            v1 = lane < NL - 64 ? s_v[64 + lane] : 0;
+            flags |= FLAG_PLOW_EXACT;
+            low_folded = true;
+        }
     }
     // every input word has been read (into registers) before the first output word is written: out may alias sets
     WaveFinish r = finish_wave(v0, v1, flags);
@@ -604,16 +620,21 @@ static hipError_t launch_exdot(Ctx &c, const double *a, long long inca, const do
     return hipGetLastError();
 }
 
-hipError_t finalize_groups(Ctx &c, hipStream_t st, long long *d_out)
+// d_low_out == nullptr: the context's low accumulator (ExDOT products below 2^-968) is folded into the record;
+// otherwise it is exported as a digit set (SET_WORDS int64) and the record holds the main digits alone
+hipError_t finalize_groups(Ctx &c, hipStream_t st, long long *d_out, long long *d_low_out)
 {
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, st, c.gacc, c.ngroups, NL, c.gflags, 0u, 1, d_out);
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, st, c.gacc, c.ngroups, NL, c.gflags, 0u, 1, d_out,
+                       (const long long *)nullptr, d_low_out);
     return hipGetLastError();
 }
 
-hipError_t finalize_sets(const long long *d_sets, int nsets, unsigned flags_or, hipStream_t st, long long *d_out)
+// d_low_set: the sum of the ranks' exported low digit sets (folded when the flags say products underflowed), or nullptr
+hipError_t finalize_sets(const long long *d_sets, int nsets, unsigned flags_or, hipStream_t st, long long *d_out,
+                         const long long *d_low_set)
 {
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, st, const_cast<long long *>(d_sets), nsets, SET_WORDS,
-                       (unsigned *)nullptr, flags_or, 0, d_out);
+                       (unsigned *)nullptr, flags_or, 0, d_out, d_low_set, (long long *)nullptr);
     return hipGetLastError();
 }
 

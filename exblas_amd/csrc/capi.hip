@@ -141,6 +141,8 @@ Ctx &ctx(int device, int layer)
     return c;
 }
 
+Ctx &default_ctx() { return ctx(-1); }
+
 void *stage_buf(Ctx &c, int slot, size_t bytes)
 {
     if (bytes > c.stage_bytes[slot]) {

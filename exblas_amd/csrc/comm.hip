@@ -108,6 +108,9 @@ struct exblas_comm {
     hipEvent_t ev_acc[2] = {nullptr, nullptr}, ev_zero[2] = {nullptr, nullptr};
     bool zero_pending[2] = {false, false};
     int pipe_slot = 0;
+    // the low digit set of a reduction in flight (ExDOT products below 2^-968), one per accumulator slot: all-reduced
+    // beside the main digit set so that the result stays bit-identical for every rank count in that corner too
+    long long *xlow = nullptr;
     // host transport bounce buffer (pinned)
     void *bounce = nullptr;
     size_t bounce_bytes = 0;
@@ -136,6 +139,14 @@ static int comm_side(exblas_comm *cm)
         if ((e = hipEventCreateWithFlags(&cm->ev_done, hipEventDisableTiming)) != hipSuccess) return (int)e;
     }
     return 0;
+}
+
+static int comm_xlow(exblas_comm *cm)
+{
+    if (cm->xlow) return 0;
+    hipError_t e = hipMalloc(&cm->xlow, 2 * SET_WORDS * sizeof(long long));
+    if (e == hipSuccess) e = hipMemset(cm->xlow, 0, 2 * SET_WORDS * sizeof(long long));
+    return (int)e;
 }
 
 static int comm_pipe(exblas_comm *cm)
@@ -194,6 +205,22 @@ static int comm_allreduce_i64(exblas_comm *cm, long long *d_buf, size_t count, h
         return nccl_rc(rccl().AllReduce(d_buf, d_buf, count, ncclInt64, ncclSum, cm->nccl, st), "ncclAllReduce");
     return via_host(cm, d_buf, count * sizeof(long long), st,
                     [&](void *h) { return cm->h_allreduce(cm->user, (int64_t *)h, (int64_t)count); });
+}
+
+// the main and the low digit set of one reduction: two buffers, ONE launch (group call) on the RCCL transport
+static int comm_allreduce_sets(exblas_comm *cm, long long *d_main, long long *d_low, hipStream_t st)
+{
+    if (cm->nranks == 1 && cm->kind == 1 && !cm->h_allreduce) return 0;
+    if (cm->kind == 0) {
+        RcclApi &a = rccl();
+        int rc = nccl_rc(a.GroupStart(), "ncclGroupStart");
+        if (!rc) rc = nccl_rc(a.AllReduce(d_main, d_main, SET_WORDS, ncclInt64, ncclSum, cm->nccl, st), "ncclAllReduce");
+        if (!rc) rc = nccl_rc(a.AllReduce(d_low, d_low, SET_WORDS, ncclInt64, ncclSum, cm->nccl, st), "ncclAllReduce(low)");
+        const int rc2 = nccl_rc(a.GroupEnd(), "ncclGroupEnd");
+        return rc ? rc : rc2;
+    }
+    int rc = comm_allreduce_i64(cm, d_main, SET_WORDS, st);
+    return rc ? rc : comm_allreduce_i64(cm, d_low, SET_WORDS, st);
 }
 
 static int comm_bcast(exblas_comm *cm, void *d_buf, size_t bytes, int root, hipStream_t st)
@@ -340,6 +367,7 @@ int exblas_comm_destroy(exblas_comm_t *cm)
         }
     }
     if (cm->bounce) (void)hipHostFree(cm->bounce);
+    if (cm->xlow) (void)hipFree(cm->xlow);
     int rc = 0;
     if (cm->kind == 0 && cm->owned && cm->nccl) rc = nccl_rc(rccl().CommDestroy(cm->nccl), "ncclCommDestroy");
     delete cm;
@@ -362,13 +390,20 @@ int exblas_allreduce_finish_dev(exblas_comm_t *cm, void *stream, int64_t *d_out)
 {
     if (!cm) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream;
-    int rc = exblas_finish_dev(stream, d_out);
-    if (rc) return rc;
     std::lock_guard<std::mutex> lk(cm->mu);
-    rc = comm_allreduce_i64(cm, (long long *)d_out + OUT_DIGITS, SET_WORDS, st);
+    int rc = comm_xlow(cm);
+    if (rc) return rc;
+    Ctx &c = default_ctx();
+    long long *low = cm->xlow + (size_t)c.slot * SET_WORDS;
+    {
+        std::lock_guard<std::mutex> lc(c.mu);
+        rc = (int)finalize_groups(c, st, (long long *)d_out, low);   // main digits in the record, low digits exported
+    }
+    if (rc) return rc;
+    rc = comm_allreduce_sets(cm, (long long *)d_out + OUT_DIGITS, low, st);
     if (rc) return rc;
     // in place: k_finalize reads every input word before it writes the first output word
-    return (int)finalize_sets((const long long *)d_out + OUT_DIGITS, 1, 0u, st, (long long *)d_out);
+    return (int)finalize_sets((const long long *)d_out + OUT_DIGITS, 1, 0u, st, (long long *)d_out, low);
 }
 
 // ---- pipelined form: the second half of reduction i runs on the communicator's side stream beside the streaming
@@ -401,10 +436,17 @@ static int pipelined_step(exblas_comm_t *cm, const double *d_a, int64_t inca, co
     e = hipEventRecord(cm->ev_acc[slot], st);
     if (e == hipSuccess) e = hipStreamWaitEvent(cm->side, cm->ev_acc[slot], 0);
     if (e != hipSuccess) return (int)e;
-    // normalise the slot (leaves it zero), all-reduce, carry-propagate + round: on the side stream
-    if ((rc = exblas_finish_dev(cm->side, d_out)) != 0) return rc;
-    if ((rc = comm_allreduce_i64(cm, (long long *)d_out + OUT_DIGITS, SET_WORDS, cm->side)) != 0) return rc;
-    if ((rc = (int)finalize_sets((const long long *)d_out + OUT_DIGITS, 1, 0u, cm->side, (long long *)d_out)) != 0) return rc;
+    // normalise the slot (leaves it zero), all-reduce main + low digit sets, carry-propagate + round: on the side stream
+    if ((rc = comm_xlow(cm)) != 0) return rc;
+    long long *low = cm->xlow + (size_t)slot * SET_WORDS;
+    {
+        Ctx &c = default_ctx();
+        std::lock_guard<std::mutex> lc(c.mu);
+        rc = (int)finalize_groups(c, cm->side, (long long *)d_out, low);
+    }
+    if (rc) return rc;
+    if ((rc = comm_allreduce_sets(cm, (long long *)d_out + OUT_DIGITS, low, cm->side)) != 0) return rc;
+    if ((rc = (int)finalize_sets((const long long *)d_out + OUT_DIGITS, 1, 0u, cm->side, (long long *)d_out, low)) != 0) return rc;
     e = hipEventRecord(cm->ev_zero[slot], cm->side);
     cm->zero_pending[slot] = e == hipSuccess;
     return (int)e;

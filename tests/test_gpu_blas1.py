@@ -513,10 +513,10 @@ def test_exdot_underflowing_products_are_summed_exactly(ex, oracle):
 
 
 def test_exdot_flags_survive_the_digit_set(ex):
-    """The product flags travel with the 576-byte digit set (its pad word), so an all-reduced result carries the OR over
-    the ranks.  What does NOT travel is the sub-2^-1074 remainder of a rank's low accumulator (the digit set holds the
-    main digits): a multi-rank result with bit 3 set and bit 5 clear is the correctly rounded sum of the ranks' values
-    truncated at 2^-1074 -- the round-2 fence."""
+    """The product flags travel with the 576-byte digit set (its pad word).  exblas_finalize_dev on user-held digit sets
+    has no low sets to fold: a result with bit 3 but not bit 5 is the correctly rounded sum of the sets' values, each
+    truncated at 2^-1074 (the library's own multi-rank calls all-reduce the low digit sets too and stay exact:
+    tests/test_gpu_multirank.py)."""
     import torch
     a = torch.tensor([2.0 ** -500, 1.0], dtype=torch.float64, device="cuda")
     b = torch.tensor([2.0 ** -490, 3.0], dtype=torch.float64, device="cuda")

@@ -53,6 +53,23 @@ def _run_all(ex, torch, comm, rank, world):
         for name, r in (("sum", rs), ("dot", rd)):
             rec = ex.read_record(r)
             out[f"{name}{fpe}"] = (rec.exact, rec.refmode, rec.canon.tolist())
+    # products below 2^-968 (their low parts live in the LOW accumulator): every rank exports its low digit set, both sets
+    # are all-reduced, the fold happens once -- the same 8 bytes and flag bits 3 + 5 for every rank count
+    nu = 200000 + 6
+    xu = ex.gen_dev("fpuniform_signed", nu, 91, 40, 20)
+    yu = ex.gen_dev("fpuniform_signed", nu, 92, 40, 20)
+    xu[: nu // 2] *= 2.0 ** -520
+    yu[: nu // 2] *= 2.0 ** -500
+    u0, u1 = ex.shard_range(nu, rank, world)
+    for fpe, ee in ((8, True), (0, False), (4, False)):
+        r = ex.exdot_dev(xu, yu, fpe, ee) if comm is None else ex.exdot_allreduce(comm, xu[u0:u1], yu[u0:u1], fpe, ee)
+        rec = ex.read_record(r)
+        assert rec.flags == 8 | 32, rec.flags
+        out[f"dot_under{fpe}"] = (rec.exact, rec.flags)
+    if comm is None:
+        from oracle import pyoracle as O
+        if O.mpfr() is not None:
+            assert out["dot_under8"][0] == O.mpfr_exdot(xu.cpu().numpy(), yu.cpu().numpy())
     r0, r1 = ex.row_block(M, rank, world)
     c0, c1 = ex.row_block(N, rank, world)
     for fpe, ee in ((8, True), (0, False), (4, False)):
