@@ -5,7 +5,8 @@
 // (:142-152, :266-273) and the root rounds.  Here the same three steps run on the GPUs:
 //   * every rank reduces its shard with the streaming kernels and normalises (k_finalize) -> 72 int64 words
 //     (68 digits < 2^32 + 3 non-finite indicators) that never leave HBM;
-//   * ONE int64-sum all-reduce of those 576 bytes (RCCL over xGMI: ncclAllReduce(ncclInt64, ncclSum) on the caller's
+//   * ONE int64-sum all-reduce launch over those 576 bytes and the 576 bytes of the LOW digit set (ExDOT products below
+//     2^-968; all zero otherwise) (RCCL over xGMI: a group of two ncclAllReduce(ncclInt64, ncclSum) on the caller's
 //     stream).  Integer addition is associative and commutative, so ring/tree order, GPU count and shard boundaries
 //     cannot change a bit; digits < 2^32 leave room for 2^31 ranks;
 //   * every rank runs the same carry-propagation + rounding kernel on the summed digits.

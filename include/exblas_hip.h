@@ -55,13 +55,14 @@ extern "C" {
 #define EXBLAS_OUT_FLAGS 2    /* bit0 +inf, bit1 -inf, bit2 NaN seen in the input.  ExDOT also:
                                * bit3 (PRODUCT_UNDERFLOW) = a product of two non-zero operands was below 2^-968, i.e. had bits
                                *   below 2^-1074, the last place of the double-range accumulator;
-                               * bit5 (PRODUCT_LOW_EXACT), set with bit3 by a single-device reduction = those products lost
-                               *   nothing: each was formed again at a scaled exponent (error-free) and summed in a second,
-                               *   LOW accumulator that the finalize kernel folded back (its part below 2^-1074 as the half /
-                               *   sticky bits of the rounding) -- the result is the correctly rounded EXACT dot product.  With
-                               *   bit3 alone (a multi-rank result: the 576-byte digit set carries the main digits, not a
-                               *   rank's sub-2^-1074 remainder) it is the correctly rounded sum of the ranks' values truncated
-                               *   at 2^-1074;
+                               * bit5 (PRODUCT_LOW_EXACT), set with bit3 = those products lost nothing: each was formed again
+                               *   at a scaled exponent (error-free) and summed in a second, LOW accumulator that the finalize
+                               *   kernel folded back (its part below 2^-1074 as the half / sticky bits of the rounding) -- the
+                               *   result is the correctly rounded EXACT dot product.  The library's multi-rank calls all-reduce
+                               *   the low digit set beside the main one, so this holds for every rank count.  Bit3 WITHOUT bit5
+                               *   only arises where low sets were not available -- exblas_finalize_dev on user-held digit sets,
+                               *   a host-pointer exdot spread over several devices -- and means: the correctly rounded sum of
+                               *   the parts' values, each truncated at 2^-1074;
                                * bit4 (PRODUCT_OVERFLOW) = a product of two FINITE operands overflowed: the result is +-Inf / NaN
                                *   as in IEEE arithmetic although the exact sum may be finite.
                                * No bit, or bits 3 + 5: the result is the MPFR-4196 value of tests/test.exdot.gpu.cpp:24-46.
@@ -245,7 +246,8 @@ int exblas_last_gemm_info_ctx(exblas_ctx_t *ctx, int *out8);
 /* ---- (2b) multi-GPU: one process per GPU ----------------------------------------------------- */
 /* The reference reduces across processes inside the library call: local reduction, MPI_Reduce(MPI_LONG, MPI_SUM) of
  * the normalised limbs, Round on the root (src/cpu/blas/blas1/ExSUM.cpp:142-152, :266-273; scatter :33-63).  Here:
- * local reduction on each GPU, ONE int64-sum all-reduce of the 576-byte digit set, the same carry-propagation +
+ * local reduction on each GPU, ONE int64-sum all-reduce launch over the two 576-byte digit sets (main digits; low digits = ExDOT products below
+ * 2^-968, all zero otherwise), the same carry-propagation +
  * rounding kernel on every rank.  Integer addition is order-free, so the result is bit-identical for any number of
  * ranks and any shard boundaries.  ExGEMV / ExGEMM shard the outputs (no reduction collective): x resp. B is
  * replicated by one broadcast, y resp. C completed by an all-gather that overlaps the remaining compute.
