@@ -535,7 +535,7 @@ static void run_exsum(Ctx &c, const double *a, long long n, hipStream_t st)
     // resident blocks per CU: the HBM-bound kernels want few fat blocks; the variants that run the full N-level cascade
     // on every element (no early exit, N >= 5: 30-48 dependent fp64 adds per element) are VALU-latency-bound and want
     // more waves per SIMD to hide it
-    const int bpc = N == 0 ? c.bpc_sa : ((!EE && N >= 5) ? c.bpc_heavy : c.bpc_sum);
+    const int bpc = N == 0 ? c.bpc_sa : ((!SKIP_ZERO_LEVELS<EE> && N >= 5) ? c.bpc_heavy : c.bpc_sum);
     int grid = grid_for(c, n, (long long)BLOCK * 2 * U, bpc);
     // an odd number of workgroups (one resident slot left idle): the tiles a workgroup has in flight are grid x 16 KiB
     // apart, and with an even grid they compete for the same HBM channels -- 865 against 855 Gelem/s at n = 2^28
@@ -544,10 +544,16 @@ static void run_exsum(Ctx &c, const double *a, long long n, hipStream_t st)
                        c.ngroups, c.variant == 9 ? 1 : 0);
 }
 
+#ifndef EXBLAS_SUM_COPIES
+#define EXBLAS_SUM_COPIES 8
+#endif
+#ifndef EXBLAS_DOT_COPIES
+#define EXBLAS_DOT_COPIES 8
+#endif
 template <int N, bool EE>
 static hipError_t launch_exsum(Ctx &c, const double *a, long long n, long long inca, hipStream_t st)
 {
-    constexpr int COPIES = (N == 0) ? 16 : 8;
+    constexpr int COPIES = (N == 0) ? 16 : EXBLAS_SUM_COPIES;
     if (inca == 1) {
         if constexpr (N == 8 && EE) {
             // tuning variants of the production kernel, selected with exblas_set_tuning() for A/B runs
@@ -591,7 +597,7 @@ template <int N, bool EE>
 static hipError_t launch_exdot(Ctx &c, const double *a, long long inca, const double *b, long long incb,
                                long long n, hipStream_t st)
 {
-    constexpr int COPIES = (N == 0) ? 16 : 8;
+    constexpr int COPIES = (N == 0) ? 16 : EXBLAS_DOT_COPIES;
     const bool vec = inca == 1 && incb == 1 && (((uintptr_t)a | (uintptr_t)b) & 15u) == 0;
     if (vec) {
         if constexpr (N == 8 && EE) {
@@ -610,7 +616,7 @@ static hipError_t launch_exdot(Ctx &c, const double *a, long long inca, const do
             default: run_exdot<N, EE, COPIES, 4, true, true, 1, false, 1>(c, a, b, n, st); break;
             }
         } else {
-            run_exdot<N, EE, COPIES, 4, true, true, 1, false, EE ? 1 : 0>(c, a, b, n, st);
+            run_exdot<N, EE, COPIES, 4, true, true, 1, false, SKIP_ZERO_LEVELS<EE> ? 1 : 0>(c, a, b, n, st);
         }
     } else {
         int grid = grid_for(c, n, BLOCK, c.blocks_per_cu);

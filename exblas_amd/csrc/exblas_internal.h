@@ -18,7 +18,7 @@ struct Ctx {
     // blocks (2 per CU: 7.15 TB/s vs 6.46 at 8), the two-stream ExDOT kernel with many (16-32 per CU).
     int bpc_sum = 2, bpc_dot = 48;   // ExDOT: 48 (an odd grid of 12289 workgroups) edges out 32 by ~1 %, 16 and 96 lose 2-3 %
     int bpc_sa = 3;          // superaccumulator-only ExSUM (LDS-atomic bound; 3/CU: 6.65 TB/s, 2/CU: 6.0)
-    int bpc_heavy = 4;       // ExSUM variants without early exit, N >= 5 (VALU-latency-bound)
+    int bpc_heavy = 4;       // ExSUM variants without early exit, N >= 5, in -DEXBLAS_FULL_CASCADE=1 builds only (VALU-latency-bound)
     int ngroups = 32;        // EXBLAS_NGROUPS: global group accumulators the blocks add into
     int grid_adj = 0;        // EXBLAS_GRID_ADJ: workgroups added to the grid of the streaming ExSUM / ExDOT kernels
     int variant = 0;         // tuning variant of the production kernels (exblas_set_tuning)

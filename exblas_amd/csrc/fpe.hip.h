@@ -165,9 +165,20 @@ __device__ __forceinline__ bool fpe_guard(double &a0, const double (&x)[CNT], co
     return true;
 }
 
-// Push CNT elements (a "tile") through expansion levels from..N-1.  EE: one wave-uniform test per
-// level per tile ends the cascade as soon as every residue of every lane is zero.
+// Push CNT elements (a "tile") through expansion levels from..N-1.  One wave-uniform test per level per tile ends the
+// cascade as soon as every residue of every lane is zero.  Skipping a level whose incoming terms are all zero is the
+// IDENTITY on the expansion (TwoSum(a, 0) = (a, 0)), so the registers evolve bit for bit as in the full cascade: the
+// variants WITHOUT early exit take the same shortcut (round 3; before, they ran all N levels on every tile and `fpe = 8`
+// streamed at 3.9-4.5 TB/s where `fpe = 8, early_exit` reached 6.7 -- for identical registers).  `early_exit` therefore
+// only selects the expansion size (4 / 6 / 8 against N = fpe), as gpu:ExSUM.cpp:72-83 does.  -DEXBLAS_FULL_CASCADE=1
+// builds the library with the unconditional N-level cascade for EE = false (A/B measurements).
 // Returns (wave-uniform) whether anything had to be spilled to the integer accumulator.
+#ifndef EXBLAS_FULL_CASCADE
+#define EXBLAS_FULL_CASCADE 0
+#endif
+template <bool EE>
+inline constexpr bool SKIP_ZERO_LEVELS = EE || !EXBLAS_FULL_CASCADE;
+
 template <int N, bool EE, int CNT, class Sink, int ZM = 0>
 __device__ __forceinline__ bool fpe_cascade(double (&a)[N > 0 ? N : 1], double (&x)[CNT], int from, Sink &sink)
 {
@@ -181,7 +192,7 @@ __device__ __forceinline__ bool fpe_cascade(double (&a)[N > 0 ? N : 1], double (
                 a[i] = two_sum(a[i], x[j], s);
                 x[j] = s;
             }
-            if (EE && i > from) live = __any(any_nonzero<CNT, ZM>(x));  // wave-uniform
+            if (SKIP_ZERO_LEVELS<EE> && i > from) live = __any(any_nonzero<CNT, ZM>(x));  // wave-uniform
         }
     }
     // what survived every level goes to the integer accumulator (rare: one wave-uniform test first)
@@ -212,15 +223,26 @@ __device__ __forceinline__ bool fpe_absorb_sink(double (&a)[N > 0 ? N : 1], doub
 // which on gfx950 streams at ~6 TB/s on its own -- before the expansion is tried again; every spill in a row doubles
 // the length of the bypass (BYPASS_MIN .. BYPASS_MAX tiles), a tile the expansion absorbs resets it.  Wide-range inputs
 // then cost what the superaccumulator-only variant costs instead of N TwoSum levels PLUS the spill per element;
-// well-conditioned inputs never take the branch.  This is a property of the DATA, not of the variant: the N-level
-// cascade of a variant without early exit is run, unconditionally and in full, on every tile the expansion is tried on
+// well-conditioned inputs never take the branch.  This is a property of the DATA, not of the variant
 // (the reference's FPE kernels flush the whole expansion per surviving element instead, ExSUM.FPE.cl:262-292).
 // The sum is exact either way, and so are the limbs the parity tests compare.
-constexpr int BYPASS_MIN = 63, BYPASS_MAX = 4095;
+#ifndef EXBLAS_BYPASS_MIN
+#define EXBLAS_BYPASS_MIN 63
+#define EXBLAS_BYPASS_MAX 4095
+#endif
+constexpr int BYPASS_MIN = EXBLAS_BYPASS_MIN, BYPASS_MAX = EXBLAS_BYPASS_MAX;   // (macros: A/B builds, tools/ab_build.sh)
 
+// Measured and dropped (round 3): a word shared by the launches of one reduction that the first
+// spilling wave sets and that makes later waves START in bypass mode (wide-range rows 5.5-5.8 -> 4.2 TB/s); other spans
+// (7..63, 15..255, 255..4095) and 4 or 16 accumulator copies per wave: within +-3 % (4 copies: -6 %).
 struct Bypass {
     int left = 0;    // tiles still to go straight to the integer accumulator (wave-uniform)
     int span = BYPASS_MIN;
+    __device__ __forceinline__ void spilled()
+    {
+        left = span;
+        span = min(2 * span + 1, BYPASS_MAX);
+    }
 };
 
 template <int N, bool EE, int CNT, class Sink, int ZM = 0>
@@ -234,8 +256,7 @@ __device__ __forceinline__ void fpe_absorb_adaptive(double (&a)[N > 0 ? N : 1], 
 #pragma unroll
             for (int j = 0; j < CNT; ++j) sink.add(x[j]);
         } else if (fpe_absorb_sink<N, EE, CNT, Sink, ZM>(a, x, 0, sink)) {
-            bp.left = bp.span;
-            bp.span = min(2 * bp.span + 1, BYPASS_MAX);
+            bp.spilled();
         } else {
             bp.span = BYPASS_MIN;
         }
@@ -278,8 +299,7 @@ __device__ __forceinline__ void fpe_absorb_prod_adaptive(double (&a)[N > 0 ? N :
                 sink_product(sink, p[j], e[j]);
             }
         } else if (fpe_absorb_prod<N, EE, CNT, Sink, ZM>(a, p, e, sink)) {
-            bp.left = bp.span;
-            bp.span = min(2 * bp.span + 1, BYPASS_MAX);
+            bp.spilled();
         } else {
             bp.span = BYPASS_MIN;
         }

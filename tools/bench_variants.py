@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Throughput of every (fpe, early_exit) variant of ExSUM / ExDOT on several input distributions.
-usage: python tools/bench_variants.py [log2n]   -> markdown table on stdout"""
+usage: python tools/bench_variants.py [log2n] [wide]   -> markdown table on stdout ("wide": only the rows that spill;
+EXBLAS_AMD_LIB=<path> selects an A/B build of the library, tools/ab_build.sh)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -8,11 +9,13 @@ import exblas_amd as ex
 lg = int(sys.argv[1]) if len(sys.argv) > 1 else 27
 n = 1 << lg
 data = [("naive", 0.0, 0.0), ("ill_cond", 1e32, 0.0), ("lognormal", 0.0, 2.0), ("lognormal", 0.0, 50.0), ("fpuniform_signed", 1800.0, 900.0)]
+if len(sys.argv) > 2 and sys.argv[2] == "wide":
+    data = [d for d in data if d[2] == 50.0 or d[1] in (1e32, 1800.0)]
 sum_var = [(0, False), (2, False), (3, False), (4, False), (8, False), (4, True), (6, True), (8, True)]
 dot_var = [(0, False), (3, False), (4, False), (8, False), (4, True), (6, True), (8, True)]
 
 
-def t(fn, reps=5):
+def t(fn, reps=20):
     fn(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
