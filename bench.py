@@ -10,7 +10,7 @@ With --gpus N > 1 and no WORLD_SIZE in the environment the script launches its o
 with the child's status; it refuses (exit 2) when the box has fewer than N devices.  It never degrades to fewer ranks.
 
 A "step" is one pass of the hot path over one of the synthetic vectors: the streaming kernel, the finalize
-kernel and -- for N > 1 -- the int64 all-reduce of the two 576-byte digit sets (main + low) plus the re-finalize, all issued by
+kernel and -- for N > 1 -- the int64 all-reduce of the three 576-byte digit sets (main + low + high) plus the re-finalize, all issued by
 libexblas.so (exblas_exsum_accumulate_dev + exblas_allreduce_finish_dev: ncclAllReduce on a HIP stream, no
 torch.distributed in the step).  --rotate (default 4) DISTINCT vectors are cycled through, so no step can be served by
 the 256 MiB Infinity Cache from the previous one.  The same-buffer variant (every step re-reads one vector) is measured
@@ -743,10 +743,10 @@ def main():
                 par = "single"
             elif strong:
                 shape = f"ONE vector of n=2^{args.log2n} partitioned n/{world} (exblas_shard_range)"
-                par = f"shard{world} of one vector, two 576-byte digit sets (main + low) all-reduced per step"
+                par = f"shard{world} of one vector, three 576-byte digit sets (main + low + high) all-reduced per step"
             else:
                 shape = f"n=2^{args.log2n} per GPU ({world}*2^{args.log2n} in all)"
-                par = f"shard{world}, 2^{args.log2n} elements per GPU, two 576-byte digit sets (main + low) all-reduced per step"
+                par = f"shard{world}, 2^{args.log2n} elements per GPU, three 576-byte digit sets (main + low + high) all-reduced per step"
             out = {
                 "metric": f"{opname} fp64 Gelem/s at n=2^{args.log2n} (bit-exact vs CPU superaccumulator/MPFR)",
                 "value": head["value"],

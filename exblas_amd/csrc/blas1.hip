@@ -204,7 +204,7 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_exdot(const double *__restrict__
     long long *col = s_acc + wave * NL * COPIES + (lane & (COPIES - 1));
     unsigned flags = 0;
     LdsSink<COPIES> sink{col, flags};
-    long long *const lo_acc = low_acc_of(gflags);   // exact home of products below 2^-968 (prod_underflow_divert)
+    long long *const lo_acc = low_acc_of(gflags), *const hi_acc = high_acc_of(gflags);   // exact homes of the products below 2^-968 / beyond the double range (prod_range_divert)
     double fpe[N > 0 ? N : 1];
 #pragma unroll
     for (int i = 0; i < (N > 0 ? N : 1); ++i) fpe[i] = 0.0;
@@ -230,9 +230,9 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_exdot(const double *__restrict__
                 x[2 * u] = two_prod(ra[u].x, rb[u].x, e[2 * u]);
                 x[2 * u + 1] = two_prod(ra[u].y, rb[u].y, e[2 * u + 1]);
             }
-            if (!prod_underflow_divert<2 * U>(x, e, sink, lo_acc, [&](int j) { return j & 1 ? ra[j >> 1].y : ra[j >> 1].x; },
+            if (!prod_range_divert<2 * U>(fpe[0], x, e, sink, lo_acc, hi_acc, [&](int j) { return j & 1 ? ra[j >> 1].y : ra[j >> 1].x; },
                                               [&](int j) { return j & 1 ? rb[j >> 1].y : rb[j >> 1].x; }))
-                fpe_absorb_prod_adaptive<N, EE, 2 * U>(fpe, x, e, sink, bypass);
+                fpe_absorb_prod_adaptive<N, EE, 2 * U, LdsSink<COPIES>, 0, false>(fpe, x, e, sink, bypass);
         }
     } else {
         long long t = blockIdx.x;
@@ -259,8 +259,7 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_exdot(const double *__restrict__
                         x[2 * u] = two_prod(ra[h * H + u].x, rb[h * H + u].x, e[2 * u]);
                         x[2 * u + 1] = two_prod(ra[h * H + u].y, rb[h * H + u].y, e[2 * u + 1]);
                     }
-                    const bool diverted = prod_underflow_divert<2 * H>(
-                        x, e, sink, lo_acc, [&](int j) { return j & 1 ? ra[h * H + (j >> 1)].y : ra[h * H + (j >> 1)].x; },
+                    const bool diverted = prod_range_divert<2 * H>(fpe[0], x, e, sink, lo_acc, hi_acc, [&](int j) { return j & 1 ? ra[h * H + (j >> 1)].y : ra[h * H + (j >> 1)].x; },
                         [&](int j) { return j & 1 ? rb[h * H + (j >> 1)].y : rb[h * H + (j >> 1)].x; });
                     if (tn < ntiles) {
                         const long long base = tn * TILE + threadIdx.x;
@@ -270,7 +269,7 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_exdot(const double *__restrict__
                             rb[h * H + u] = ld2<NT>(vb + base + (h * H + u) * BLOCK);
                         }
                     }
-                    if (!diverted) fpe_absorb_prod_adaptive<N, EE, 2 * H>(fpe, x, e, sink, bypass);
+                    if (!diverted) fpe_absorb_prod_adaptive<N, EE, 2 * H, LdsSink<COPIES>, 0, false>(fpe, x, e, sink, bypass);
                 }
                 t = tn;
             }
@@ -294,9 +293,9 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_exdot(const double *__restrict__
                     x[2 * u] = two_prod(pa[u].x, pb[u].x, e[2 * u]);
                     x[2 * u + 1] = two_prod(pa[u].y, pb[u].y, e[2 * u + 1]);
                 }
-                if (!prod_underflow_divert<2 * U>(x, e, sink, lo_acc, [&](int j) { return j & 1 ? pa[j >> 1].y : pa[j >> 1].x; },
+                if (!prod_range_divert<2 * U>(fpe[0], x, e, sink, lo_acc, hi_acc, [&](int j) { return j & 1 ? pa[j >> 1].y : pa[j >> 1].x; },
                                                   [&](int j) { return j & 1 ? pb[j >> 1].y : pb[j >> 1].x; }))
-                    fpe_absorb_prod_adaptive<N, EE, 2 * U, LdsSink<COPIES>, ZM>(fpe, x, e, sink, bypass);
+                    fpe_absorb_prod_adaptive<N, EE, 2 * U, LdsSink<COPIES>, ZM, false>(fpe, x, e, sink, bypass);
             };
             for (;;) {
                 fill(t + gridDim.x, rc, rd);
@@ -316,14 +315,14 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_exdot(const double *__restrict__
         double x[2], e[2];
         x[0] = two_prod(ra.x, rb.x, e[0]);
         x[1] = two_prod(ra.y, rb.y, e[1]);
-        if (!prod_underflow_divert<2>(x, e, sink, lo_acc, [&](int j) { return j ? ra.y : ra.x; }, [&](int j) { return j ? rb.y : rb.x; }))
-            fpe_absorb_prod<N, false, 2>(fpe, x, e, sink);
+        if (!prod_range_divert<2>(fpe[0], x, e, sink, lo_acc, hi_acc, [&](int j) { return j ? ra.y : ra.x; }, [&](int j) { return j ? rb.y : rb.x; }))
+            fpe_absorb_prod<N, false, 2, LdsSink<COPIES>, 0, false>(fpe, x, e, sink);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0 && (n & 1)) {
         double x1[1], e1[1];
         x1[0] = two_prod(a[n - 1], b[n - 1], e1[0]);
         // (only this lane is active: the helper's votes are votes of one)
-        if (!prod_underflow_divert<1>(x1, e1, sink, lo_acc, [&](int) { return a[n - 1]; }, [&](int) { return b[n - 1]; }))
+        if (!prod_range_divert<1>(fpe[0], x1, e1, sink, lo_acc, hi_acc, [&](int) { return a[n - 1]; }, [&](int) { return b[n - 1]; }))
             sink_product(sink, x1[0], e1[0]);
     }
     fpe_flush<N, COPIES>(fpe, col, flags);
@@ -343,7 +342,7 @@ __global__ void __launch_bounds__(BLOCK) k_exdot_strided(const double *__restric
     long long *col = s_acc + wave * NL * COPIES + (lane & (COPIES - 1));
     unsigned flags = 0;
     LdsSink<COPIES> sink{col, flags};
-    long long *const lo_acc = low_acc_of(gflags);
+    long long *const lo_acc = low_acc_of(gflags), *const hi_acc = high_acc_of(gflags);
     double fpe[N > 0 ? N : 1];
 #pragma unroll
     for (int i = 0; i < (N > 0 ? N : 1); ++i) fpe[i] = 0.0;
@@ -358,8 +357,8 @@ __global__ void __launch_bounds__(BLOCK) k_exdot_strided(const double *__restric
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) x[u] = two_prod(va[u], vb[u], e[u]);
-        if (!prod_underflow_divert<4>(x, e, sink, lo_acc, [&](int j) { return va[j]; }, [&](int j) { return vb[j]; }))
-            fpe_absorb_prod<N, false, 4>(fpe, x, e, sink);
+        if (!prod_range_divert<4>(fpe[0], x, e, sink, lo_acc, hi_acc, [&](int j) { return va[j]; }, [&](int j) { return vb[j]; }))
+            fpe_absorb_prod<N, false, 4, LdsSink<COPIES>, 0, false>(fpe, x, e, sink);
     }
     fpe_flush<N, COPIES>(fpe, col, flags);
     block_epilogue<COPIES>(s_acc, flags, gacc, gflags, ngroups);
@@ -369,11 +368,12 @@ __global__ void __launch_bounds__(BLOCK) k_exdot_strided(const double *__restric
 // finalize: sum `nsets` limb vectors, ONE carry propagation, canonical limbs, rounding.
 // zero_sets: the input is the context's group accumulators -> leave them zeroed for the next call.
 // ---------------------------------------------------------------------------------------------
-// low_out (with gflags): EXPORT the context's low accumulator as a normalised digit set instead of folding it (the
-// multi-rank path all-reduces it beside the main digit set); low_in: fold THIS digit set (the all-reduced low sets).
+// ext_out (with gflags): EXPORT the context's low and high accumulators (ExDOT products beyond the accumulator's range,
+// fpe.hip.h: prod_range_divert) as two normalised digit sets [low | high] instead of folding them (the multi-rank path
+// all-reduces them beside the main digit set); ext_in: fold THESE digit sets (the all-reduced ones).
 __global__ void __launch_bounds__(64) k_finalize(long long *sets, int nsets, int set_stride, unsigned *gflags,
                                                  unsigned flags_or, int zero_sets, long long *out,
-                                                 const long long *low_in, long long *low_out)
+                                                 const long long *ext_in, long long *ext_out)
 {
     // one wavefront: lane l owns limb l and (l < 4) limb 64+l
     const int lane = threadIdx.x;
@@ -424,51 +424,88 @@ __global__ void __launch_bounds__(64) k_finalize(long long *sets, int nsets, int
         for (int i = lane; i < nsets * set_stride; i += 64) sets[i] = 0;
         if (lane == 0 && gflags) *gflags = 0;
     }
-    // ExDOT with products below 2^-968 (FLAG_PUNDER): fold the LOW accumulator in.  Its digits at or above 2^-1074 are
-    // added to the main digits exactly; what lies below becomes the half / sticky bits of the rounding.  Rare, so one
-    // lane does it with the scalar routines (two carry passes over 68 digits + one rounding).
-    __shared__ long long s_v[NL], s_lo[NL];
+    // ExDOT with products below 2^-968 (FLAG_PUNDER) or beyond the double range (FLAG_POVER): fold the LOW / HIGH
+    // accumulator in.  The high digits are added to the main digits exactly, EXT_SHIFT_DIGITS digits up (a sum that does
+    // not fit the main geometry is beyond the double range whatever follows: +-Inf); the low accumulator's digits at or
+    // above 2^-1074 are added exactly, what lies below becomes the half / sticky bits of the rounding.  Rare, so one lane
+    // does it with the scalar routines (carry passes over 68 / 106 digits + one rounding).
+    __shared__ long long s_v[NL], s_lo[NL], s_hi[NL], s_c[NL + EXT_SHIFT_DIGITS];
     __shared__ unsigned long long s_ex;
+    __shared__ int s_over;
     bool low_folded = false;
-    const bool have_low = (flags & FLAG_PUNDER) && (low_in || gflags);   // wave-uniform
-    if (low_out && !have_low) {          // export mode, nothing in the low accumulator: an all-zero set
-        low_out[lane] = 0;
-        if (lane < SET_WORDS - 64) low_out[64 + lane] = 0;
+    const bool have_low = (flags & FLAG_PUNDER) && (ext_in || gflags);   // wave-uniform
+    const bool have_high = (flags & FLAG_POVER) && (ext_in || gflags);
+    if (ext_out) {   // export mode: all-zero sets for the accumulators nothing was added to
+        if (!have_low) {
+            ext_out[lane] = 0;
+            if (lane < SET_WORDS - 64) ext_out[64 + lane] = 0;
+        }
+        if (!have_high) {
+            ext_out[SET_WORDS + lane] = 0;
+            if (lane < SET_WORDS - 64) ext_out[SET_WORDS + 64 + lane] = 0;
+        }
     }
-    if (have_low) {
-        const long long *src = low_in ? low_in : low_acc_of(gflags);
-        s_lo[lane] = src[lane];
+    if (have_low || have_high) {
+        const long long *lsrc = ext_in ? ext_in : low_acc_of(gflags);
+        const long long *hsrc = ext_in ? ext_in + SET_WORDS : high_acc_of(gflags);
+        s_lo[lane] = have_low ? lsrc[lane] : 0;
+        s_hi[lane] = have_high ? hsrc[lane] : 0;
         s_v[lane] = v0;
         if (lane < NL - 64) {
-            s_lo[64 + lane] = src[64 + lane];
+            s_lo[64 + lane] = have_low ? lsrc[64 + lane] : 0;
+            s_hi[64 + lane] = have_high ? hsrc[64 + lane] : 0;
             s_v[64 + lane] = v1;
         }
-        if (!low_in && zero_sets) {
-            long long *lo = low_acc_of(gflags);
-            lo[lane] = 0;
-            if (lane < NL - 64) lo[64 + lane] = 0;
-        }
-        __syncthreads();
-        if (lane == 0) {
-            normalize_digits(s_lo);
-            if (!low_out) {
-                for (int j = LOW_SHIFT_DIGITS; j < NL; ++j) s_v[j - LOW_SHIFT_DIGITS] += s_lo[j];
-                normalize_digits(s_v);
-                const bool half = (s_lo[LOW_SHIFT_DIGITS - 1] >> 31) & 1ll;
-                bool sticky = (s_lo[LOW_SHIFT_DIGITS - 1] & 0x7fffffffll) != 0;
-                for (int j = 0; j < LOW_SHIFT_DIGITS - 1; ++j) sticky = sticky || s_lo[j] != 0;
-                s_ex = round_exact_bits_frac(s_v, half, sticky);
+        if (!ext_in && zero_sets) {
+            long long *lo = low_acc_of(gflags), *hi = high_acc_of(gflags);
+            if (have_low) {
+                lo[lane] = 0;
+                if (lane < NL - 64) lo[64 + lane] = 0;
+            }
+            if (have_high) {
+                hi[lane] = 0;
+                if (lane < NL - 64) hi[64 + lane] = 0;
             }
         }
         __syncthreads();
-        if (low_out) {   // digits < 2^32 (the top one signed and small): sums over 2^31 ranks cannot overflow
-            low_out[lane] = s_lo[lane];
-            if (lane < SET_WORDS - 64) low_out[64 + lane] = lane < NL - 64 ? s_lo[64 + lane] : 0;
+        if (lane == 0) {
+            s_over = 0;
+            if (have_low) normalize_digits(s_lo);
+            if (have_high) normalize_digits(s_hi);
+            if (!ext_out) {
+                if (have_high) s_over = fold_high_digits(s_v, s_hi, s_c);
+                if (have_low && !s_over) {
+                    for (int j = LOW_SHIFT_DIGITS; j < NL; ++j) s_v[j - LOW_SHIFT_DIGITS] += s_lo[j];
+                    normalize_digits(s_v);
+                    const bool half = (s_lo[LOW_SHIFT_DIGITS - 1] >> 31) & 1ll;
+                    bool sticky = (s_lo[LOW_SHIFT_DIGITS - 1] & 0x7fffffffll) != 0;
+                    for (int j = 0; j < LOW_SHIFT_DIGITS - 1; ++j) sticky = sticky || s_lo[j] != 0;
+                    s_ex = round_exact_bits_frac(s_v, half, sticky);
+                }
+            }
+        }
+        __syncthreads();
+        if (ext_out) {   // digits < 2^32 (the top one signed and small): sums over 2^31 ranks cannot overflow
+            if (have_low) {
+                ext_out[lane] = s_lo[lane];
+                if (lane < SET_WORDS - 64) ext_out[64 + lane] = lane < NL - 64 ? s_lo[64 + lane] : 0;
+            }
+            if (have_high) {
+                ext_out[SET_WORDS + lane] = s_hi[lane];
+                if (lane < SET_WORDS - 64) ext_out[SET_WORDS + 64 + lane] = lane < NL - 64 ? s_hi[64 + lane] : 0;
+            }
         } else {
-            v0 = s_v[lane];
-            v1 = lane < NL - 64 ? s_v[64 + lane] : 0;
-            flags |= FLAG_PLOW_EXACT;
-            low_folded = true;
+            const int over = s_over;   // wave-uniform
+            if (over) {
+                // the exact sum is beyond the double range: it rounds to +-Inf, reported like an infinity in the input
+                flags |= over > 0 ? FLAG_PINF : FLAG_NINF;
+            } else {
+                v0 = s_v[lane];
+                v1 = lane < NL - 64 ? s_v[64 + lane] : 0;
+                low_folded = have_low;
+            }
+            if (have_low) flags |= FLAG_PLOW_EXACT;
+            if (have_high) flags |= FLAG_PHIGH_EXACT;
         }
     }
     // every input word has been read (into registers) before the first output word is written: out may alias sets
@@ -626,21 +663,22 @@ static hipError_t launch_exdot(Ctx &c, const double *a, long long inca, const do
     return hipGetLastError();
 }
 
-// d_low_out == nullptr: the context's low accumulator (ExDOT products below 2^-968) is folded into the record;
-// otherwise it is exported as a digit set (SET_WORDS int64) and the record holds the main digits alone
-hipError_t finalize_groups(Ctx &c, hipStream_t st, long long *d_out, long long *d_low_out)
+// d_ext_out == nullptr: the context's low / high accumulators (ExDOT products below 2^-968 / beyond the double range) are
+// folded into the record; otherwise they are exported as two digit sets (EXT_WORDS int64: [low | high]) and the record
+// holds the main digits alone
+hipError_t finalize_groups(Ctx &c, hipStream_t st, long long *d_out, long long *d_ext_out)
 {
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, st, c.gacc, c.ngroups, NL, c.gflags, 0u, 1, d_out,
-                       (const long long *)nullptr, d_low_out);
+                       (const long long *)nullptr, d_ext_out);
     return hipGetLastError();
 }
 
-// d_low_set: the sum of the ranks' exported low digit sets (folded when the flags say products underflowed), or nullptr
+// d_ext_sets: the sums of the ranks' exported [low | high] digit sets (folded when the flags say products left the range), or nullptr
 hipError_t finalize_sets(const long long *d_sets, int nsets, unsigned flags_or, hipStream_t st, long long *d_out,
-                         const long long *d_low_set)
+                         const long long *d_ext_sets)
 {
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, st, const_cast<long long *>(d_sets), nsets, SET_WORDS,
-                       (unsigned *)nullptr, flags_or, 0, d_out, d_low_set, (long long *)nullptr);
+                       (unsigned *)nullptr, flags_or, 0, d_out, d_ext_sets, (long long *)nullptr);
     return hipGetLastError();
 }
 

@@ -105,7 +105,7 @@ static void init_ctx(Ctx &c, int device, int layer)
     EXB_CHECK(crt_tables_upload());
     EXB_CHECK(hipMalloc(&c.gacc_all, 2 * sizeof(long long) * NL * c.ngroups));
     EXB_CHECK(hipMemset(c.gacc_all, 0, 2 * sizeof(long long) * NL * c.ngroups));
-    // per slot: the flag word (own 64-byte line) + the low accumulator of ExDOT (superacc.hip.h: low_acc_of)
+    // per slot: the flag word (own 64-byte line) + the low and high accumulators of ExDOT (superacc.hip.h: low_acc_of, high_acc_of)
     EXB_CHECK(hipMalloc(&c.gflags_all, 2 * FLAG_BLOCK_BYTES));
     EXB_CHECK(hipMemset(c.gflags_all, 0, 2 * FLAG_BLOCK_BYTES));
     c.gacc = c.gacc_all;

@@ -5,9 +5,9 @@
 // (:142-152, :266-273) and the root rounds.  Here the same three steps run on the GPUs:
 //   * every rank reduces its shard with the streaming kernels and normalises (k_finalize) -> 72 int64 words
 //     (68 digits < 2^32 + 3 non-finite indicators) that never leave HBM;
-//   * ONE int64-sum all-reduce launch over those 576 bytes and the 576 bytes of the LOW digit set (ExDOT products below
-//     2^-968; all zero otherwise) (RCCL over xGMI: a group of two ncclAllReduce(ncclInt64, ncclSum) on the caller's
-//     stream).  Integer addition is associative and commutative, so ring/tree order, GPU count and shard boundaries
+//   * ONE int64-sum all-reduce launch over those 576 bytes and the 2 x 576 bytes of the LOW and HIGH digit sets (ExDOT
+//     products below 2^-968 / beyond the double range; all zero otherwise) (RCCL over xGMI: a group of two
+//     ncclAllReduce(ncclInt64, ncclSum) on the caller's stream).  Integer addition is associative and commutative, so ring/tree order, GPU count and shard boundaries
 //     cannot change a bit; digits < 2^32 leave room for 2^31 ranks;
 //   * every rank runs the same carry-propagation + rounding kernel on the summed digits.
 // ExGEMV / ExGEMM shard the OUTPUT (rows of A and y resp. C): no reduction collective at all, only data movement --
@@ -109,9 +109,10 @@ struct exblas_comm {
     hipEvent_t ev_acc[2] = {nullptr, nullptr}, ev_zero[2] = {nullptr, nullptr};
     bool zero_pending[2] = {false, false};
     int pipe_slot = 0;
-    // the low digit set of a reduction in flight (ExDOT products below 2^-968), one per accumulator slot: all-reduced
-    // beside the main digit set so that the result stays bit-identical for every rank count in that corner too
-    long long *xlow = nullptr;
+    // the low and high digit sets of a reduction in flight (ExDOT products below 2^-968 / beyond the double range), one
+    // pair per accumulator slot: all-reduced beside the main digit set so that the result stays bit-identical for every
+    // rank count in those corners too
+    long long *xext = nullptr;   // two slots x [low | high] exported digit sets (superacc.hip.h: EXT_WORDS)
     // host transport bounce buffer (pinned)
     void *bounce = nullptr;
     size_t bounce_bytes = 0;
@@ -142,11 +143,11 @@ static int comm_side(exblas_comm *cm)
     return 0;
 }
 
-static int comm_xlow(exblas_comm *cm)
+static int comm_xext(exblas_comm *cm)
 {
-    if (cm->xlow) return 0;
-    hipError_t e = hipMalloc(&cm->xlow, 2 * SET_WORDS * sizeof(long long));
-    if (e == hipSuccess) e = hipMemset(cm->xlow, 0, 2 * SET_WORDS * sizeof(long long));
+    if (cm->xext) return 0;
+    hipError_t e = hipMalloc(&cm->xext, 2 * EXT_WORDS * sizeof(long long));
+    if (e == hipSuccess) e = hipMemset(cm->xext, 0, 2 * EXT_WORDS * sizeof(long long));
     return (int)e;
 }
 
@@ -208,20 +209,21 @@ static int comm_allreduce_i64(exblas_comm *cm, long long *d_buf, size_t count, h
                     [&](void *h) { return cm->h_allreduce(cm->user, (int64_t *)h, (int64_t)count); });
 }
 
-// the main and the low digit set of one reduction: two buffers, ONE launch (group call) on the RCCL transport
-static int comm_allreduce_sets(exblas_comm *cm, long long *d_main, long long *d_low, hipStream_t st)
+// the main digit set and the [low | high] extension sets of one reduction: two buffers, ONE launch (group call) on the
+// RCCL transport
+static int comm_allreduce_sets(exblas_comm *cm, long long *d_main, long long *d_ext, hipStream_t st)
 {
     if (cm->nranks == 1 && cm->kind == 1 && !cm->h_allreduce) return 0;
     if (cm->kind == 0) {
         RcclApi &a = rccl();
         int rc = nccl_rc(a.GroupStart(), "ncclGroupStart");
         if (!rc) rc = nccl_rc(a.AllReduce(d_main, d_main, SET_WORDS, ncclInt64, ncclSum, cm->nccl, st), "ncclAllReduce");
-        if (!rc) rc = nccl_rc(a.AllReduce(d_low, d_low, SET_WORDS, ncclInt64, ncclSum, cm->nccl, st), "ncclAllReduce(low)");
+        if (!rc) rc = nccl_rc(a.AllReduce(d_ext, d_ext, EXT_WORDS, ncclInt64, ncclSum, cm->nccl, st), "ncclAllReduce(ext)");
         const int rc2 = nccl_rc(a.GroupEnd(), "ncclGroupEnd");
         return rc ? rc : rc2;
     }
     int rc = comm_allreduce_i64(cm, d_main, SET_WORDS, st);
-    return rc ? rc : comm_allreduce_i64(cm, d_low, SET_WORDS, st);
+    return rc ? rc : comm_allreduce_i64(cm, d_ext, EXT_WORDS, st);
 }
 
 static int comm_bcast(exblas_comm *cm, void *d_buf, size_t bytes, int root, hipStream_t st)
@@ -368,7 +370,7 @@ int exblas_comm_destroy(exblas_comm_t *cm)
         }
     }
     if (cm->bounce) (void)hipHostFree(cm->bounce);
-    if (cm->xlow) (void)hipFree(cm->xlow);
+    if (cm->xext) (void)hipFree(cm->xext);
     int rc = 0;
     if (cm->kind == 0 && cm->owned && cm->nccl) rc = nccl_rc(rccl().CommDestroy(cm->nccl), "ncclCommDestroy");
     delete cm;
@@ -392,19 +394,19 @@ int exblas_allreduce_finish_dev(exblas_comm_t *cm, void *stream, int64_t *d_out)
     if (!cm) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream;
     std::lock_guard<std::mutex> lk(cm->mu);
-    int rc = comm_xlow(cm);
+    int rc = comm_xext(cm);
     if (rc) return rc;
     Ctx &c = default_ctx();
-    long long *low = cm->xlow + (size_t)c.slot * SET_WORDS;
+    long long *ext = cm->xext + (size_t)c.slot * EXT_WORDS;
     {
         std::lock_guard<std::mutex> lc(c.mu);
-        rc = (int)finalize_groups(c, st, (long long *)d_out, low);   // main digits in the record, low digits exported
+        rc = (int)finalize_groups(c, st, (long long *)d_out, ext);   // main digits in the record, low / high digits exported
     }
     if (rc) return rc;
-    rc = comm_allreduce_sets(cm, (long long *)d_out + OUT_DIGITS, low, st);
+    rc = comm_allreduce_sets(cm, (long long *)d_out + OUT_DIGITS, ext, st);
     if (rc) return rc;
     // in place: k_finalize reads every input word before it writes the first output word
-    return (int)finalize_sets((const long long *)d_out + OUT_DIGITS, 1, 0u, st, (long long *)d_out, low);
+    return (int)finalize_sets((const long long *)d_out + OUT_DIGITS, 1, 0u, st, (long long *)d_out, ext);
 }
 
 // ---- pipelined form: the second half of reduction i runs on the communicator's side stream beside the streaming
@@ -437,17 +439,17 @@ static int pipelined_step(exblas_comm_t *cm, const double *d_a, int64_t inca, co
     e = hipEventRecord(cm->ev_acc[slot], st);
     if (e == hipSuccess) e = hipStreamWaitEvent(cm->side, cm->ev_acc[slot], 0);
     if (e != hipSuccess) return (int)e;
-    // normalise the slot (leaves it zero), all-reduce main + low digit sets, carry-propagate + round: on the side stream
-    if ((rc = comm_xlow(cm)) != 0) return rc;
-    long long *low = cm->xlow + (size_t)slot * SET_WORDS;
+    // normalise the slot (leaves it zero), all-reduce main + low / high digit sets, carry-propagate + round: on the side stream
+    if ((rc = comm_xext(cm)) != 0) return rc;
+    long long *ext = cm->xext + (size_t)slot * EXT_WORDS;
     {
         Ctx &c = default_ctx();
         std::lock_guard<std::mutex> lc(c.mu);
-        rc = (int)finalize_groups(c, cm->side, (long long *)d_out, low);
+        rc = (int)finalize_groups(c, cm->side, (long long *)d_out, ext);
     }
     if (rc) return rc;
-    if ((rc = comm_allreduce_sets(cm, (long long *)d_out + OUT_DIGITS, low, cm->side)) != 0) return rc;
-    if ((rc = (int)finalize_sets((const long long *)d_out + OUT_DIGITS, 1, 0u, cm->side, (long long *)d_out, low)) != 0) return rc;
+    if ((rc = comm_allreduce_sets(cm, (long long *)d_out + OUT_DIGITS, ext, cm->side)) != 0) return rc;
+    if ((rc = (int)finalize_sets((const long long *)d_out + OUT_DIGITS, 1, 0u, cm->side, (long long *)d_out, ext)) != 0) return rc;
     e = hipEventRecord(cm->ev_zero[slot], cm->side);
     cm->zero_pending[slot] = e == hipSuccess;
     return (int)e;

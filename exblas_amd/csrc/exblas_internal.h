@@ -80,10 +80,10 @@ hipError_t exdot_dispatch(Ctx &c, const double *a, long long inca, const double 
                           int fpe, int early_exit, hipStream_t st, bool *supported);
 hipError_t exsum_segmented_dispatch(const double *values, const long long *offsets, long long nseg, int fpe,
                                     int early_exit, int round_mode, hipStream_t st, double *out);
-hipError_t finalize_groups(Ctx &c, hipStream_t st, long long *d_out, long long *d_low_out = nullptr);
+hipError_t finalize_groups(Ctx &c, hipStream_t st, long long *d_out, long long *d_ext_out = nullptr);
 hipError_t finalize_sets(const long long *d_sets, int nsets, unsigned flags_or, hipStream_t st, long long *d_out,
-                         const long long *d_low_set = nullptr);
-// the *_dev layer's context of the current device (comm.hip finishes its accumulators with an exported low set)
+                         const long long *d_ext_sets = nullptr);
+// the *_dev layer's context of the current device (comm.hip finishes its accumulators with exported low / high sets)
 Ctx &default_ctx();
 
 // blas2.hip / blas3.hip

@@ -95,42 +95,63 @@ __device__ __forceinline__ void sink_product(Sink &sink, double p, double e)
     }
 }
 
-// ExDOT: products of two non-zero operands below 2^-968 have bits below 2^-1074 that the accumulator cannot hold (their
-// TwoProd error term is not representable).  One exponent minimum + one wave-uniform vote per tile on the hot path; only
-// tiles that hold a tiny or zero product look at the operands (a product that underflowed to zero looks like 0 * x).
-// A tile with such a product is DIVERTED as a whole (returns true: the caller skips the expansion for it): every ordinary
-// product of the tile goes straight to the integer accumulator (exact), every tiny one is formed again at a scaled
-// exponent -- a 2^-ea (in [1/2, 1)) times b 2^(LOW_SHIFT_BITS + ea): both factors and the product are normal, so
-// TwoProd is error-free -- and added, exactly, to the LOW accumulator `lo` (global memory, the geometry of the main one,
-// unit 2^-(1074 + LOW_SHIFT_BITS)); the finalize kernel folds it back (superacc.hip.h: FLAG_PLOW_EXACT).
+// ExDOT: the exact product domain.  Products of two non-zero operands below 2^-968 have bits below 2^-1074 that the
+// accumulator cannot hold (their TwoProd error term is not representable); products of two finite operands at or above
+// 2^1024 are +-Inf as doubles.  This routine is the range guard of the ExDOT kernels (it replaces fpe_guard there: the
+// callers absorb with GUARD = false): one exponent minimum + maximum and ONE wave-uniform vote per tile on the hot path;
+// only a tile that holds a tiny, zero, huge (>= 2^1000: the expansion could overflow) or non-finite product, or an a0
+// that has reached 2^1000, looks at the operands.  Such a tile is DIVERTED as a whole (returns true: the caller skips
+// the expansion for it): every ordinary product goes straight to the integer accumulator (exact); a tiny one is formed
+// again at a scaled exponent -- a 2^-ea (in [1/2, 1)) times b 2^(ea + EXT_SHIFT_BITS): both factors and the product are
+// normal, so TwoProd is error-free -- and added, exactly, to the LOW accumulator `lo` (global memory, the geometry of
+// the main one, unit 2^-(1074 + EXT_SHIFT_BITS)); an overflowed one likewise with b 2^(ea - EXT_SHIFT_BITS) into the
+// HIGH accumulator `hi` (unit 2^(-1074 + EXT_SHIFT_BITS)); the finalize kernel folds both back (superacc.hip.h:
+// FLAG_PLOW_EXACT / FLAG_PHIGH_EXACT).  Products with an Inf / NaN OPERAND take the ordinary path (IEEE result).
 template <int CNT, class Sink, class FA, class FB>
-__device__ __forceinline__ bool prod_underflow_divert(const double (&p)[CNT], const double (&e)[CNT], Sink &sink,
-                                                      long long *lo, FA &&a_of, FB &&b_of)
+__device__ __forceinline__ bool prod_range_divert(double &a0, const double (&p)[CNT], const double (&e)[CNT], Sink &sink,
+                                                  long long *lo, long long *hi, FA &&a_of, FB &&b_of)
 {
-    unsigned mn = 0x7ffu;
+    unsigned mn = 0x7ffu, mx = expo_field(a0);
 #pragma unroll
-    for (int j = 0; j < CNT; ++j) mn = min(mn, expo_field(p[j]));
-    if (__builtin_expect(!__any(mn < LOW_EXPO), 1)) return false;
-    bool hz = false;
+    for (int j = 0; j < CNT; ++j) {
+        const unsigned ex = expo_field(p[j]);
+        mn = min(mn, ex);
+        mx = max(mx, ex);
+    }
+    if (__builtin_expect(!__any(mn < LOW_EXPO || mx >= BIG_EXPO), 1)) return false;
+    bool hz = mx >= BIG_EXPO;
 #pragma unroll
     for (int j = 0; j < CNT; ++j) hz |= expo_field(p[j]) < LOW_EXPO && a_of(j) != 0.0 && b_of(j) != 0.0;
     if (!__any(hz)) return false;   // zeros only
-    GlobalSink low{lo};
+    GlobalSink low{lo}, high{hi};
 #pragma unroll   // (unrolled although cold: a rolled loop would index the callers' register arrays dynamically = scratch memory)
     for (int j = 0; j < CNT; ++j) {
         const double a = a_of(j), b = b_of(j);
-        if (expo_field(p[j]) < LOW_EXPO && a != 0.0 && b != 0.0) {
+        const unsigned ex = expo_field(p[j]);
+        if (ex < LOW_EXPO && a != 0.0 && b != 0.0) {
             int ea;
             const double a1 = frexp(a, &ea);                       // a = a1 2^ea, 1/2 <= |a1| < 1 (subnormal a included)
-            const double b1 = ldexp(b, LOW_SHIFT_BITS + ea);       // normal: a b 2^LOW_SHIFT_BITS lies in [2^-932, 2^249)
+            const double b1 = ldexp(b, EXT_SHIFT_BITS + ea);       // normal: a b 2^EXT_SHIFT_BITS lies in [2^-932, 2^249)
             const double P = a1 * b1, E = __builtin_fma(a1, b1, -P);
             low.add(P);
             if (E != 0.0) low.add(E);
+            sink.note(FLAG_PUNDER);
+        } else if (ex == 0x7ffu && expo_field(a) != 0x7ffu && expo_field(b) != 0x7ffu) {
+            int ea;
+            const double a1 = frexp(a, &ea);
+            const double b1 = ldexp(b, ea - EXT_SHIFT_BITS);       // normal: a b 2^-EXT_SHIFT_BITS lies in [2^-192, 2^832)
+            const double P = a1 * b1, E = __builtin_fma(a1, b1, -P);
+            high.add(P);
+            if (E != 0.0) high.add(E);
+            sink.note(FLAG_POVER);
         } else {
             sink_product(sink, p[j], e[j]);
         }
     }
-    sink.note(FLAG_PUNDER);
+    if (expo_field(a0) >= BIG_EXPO) {   // (as fpe_guard: the head of the expansion never exceeds (1 + CNT) 2^1000)
+        sink.add(a0);
+        a0 = 0.0;
+    }
     return true;
 }
 
@@ -265,7 +286,7 @@ __device__ __forceinline__ void fpe_absorb_adaptive(double (&a)[N > 0 ? N : 1], 
 
 // Products: p[j] + e[j] = a_j * b_j exactly (two_prod, NOT the _safe form: the guard handles overflow).
 // The rounding errors enter the expansion at slot max(N-3, 0) like ExDOT.FPE.cl:254.
-template <int N, bool EE, int CNT, class Sink, int ZM = 0>
+template <int N, bool EE, int CNT, class Sink, int ZM = 0, bool GUARD = true>
 __device__ __forceinline__ bool fpe_absorb_prod(double (&a)[N > 0 ? N : 1], double (&p)[CNT], double (&e)[CNT],
                                                 Sink &sink)
 {
@@ -277,7 +298,9 @@ __device__ __forceinline__ bool fpe_absorb_prod(double (&a)[N > 0 ? N : 1], doub
         return false;
     } else {
         constexpr int EFROM = (N >= 3) ? N - 3 : 0;
-        if (fpe_guard<CNT>(a[0], p, e, sink)) return true;
+        if constexpr (GUARD) {   // (the ExDOT kernels run prod_range_divert first: GUARD = false)
+            if (fpe_guard<CNT>(a[0], p, e, sink)) return true;
+        }
         const bool s1 = fpe_cascade<N, EE, CNT, Sink, ZM>(a, p, 0, sink);
         const bool s2 = fpe_cascade<N, EE, CNT, Sink, ZM>(a, e, EFROM, sink);
         return s1 || s2;
@@ -285,7 +308,7 @@ __device__ __forceinline__ bool fpe_absorb_prod(double (&a)[N > 0 ? N : 1], doub
 }
 
 // adaptive form for products (see fpe_absorb_adaptive)
-template <int N, bool EE, int CNT, class Sink, int ZM = 0>
+template <int N, bool EE, int CNT, class Sink, int ZM = 0, bool GUARD = true>
 __device__ __forceinline__ void fpe_absorb_prod_adaptive(double (&a)[N > 0 ? N : 1], double (&p)[CNT],
                                                          double (&e)[CNT], Sink &sink, Bypass &bp)
 {
@@ -298,7 +321,7 @@ __device__ __forceinline__ void fpe_absorb_prod_adaptive(double (&a)[N > 0 ? N :
             for (int j = 0; j < CNT; ++j) {
                 sink_product(sink, p[j], e[j]);
             }
-        } else if (fpe_absorb_prod<N, EE, CNT, Sink, ZM>(a, p, e, sink)) {
+        } else if (fpe_absorb_prod<N, EE, CNT, Sink, ZM, GUARD>(a, p, e, sink)) {
             bp.spilled();
         } else {
             bp.span = BYPASS_MIN;

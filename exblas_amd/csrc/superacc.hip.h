@@ -40,20 +40,25 @@ constexpr int OUT_WORDS = 128;
 constexpr unsigned FLAG_PINF = 1u, FLAG_NINF = 2u, FLAG_NAN = 4u;
 // products (ExDOT): the double-range accumulator holds a 106-bit product only while it neither overflows nor reaches
 // below 2^-1074 -- the two limits the reference's kernels share (its MPFR test oracle uses 4196 bits for that reason,
-// tests/test.exdot.gpu.cpp:24-46).  They are fenced, not silent: PUNDER = some product of two non-zero operands is below
-// 2^-968 in magnitude, so bits of it below 2^-1074 were dropped (the result is then the correctly rounded sum of the
-// products truncated at 2^-1074); POVER = a product of two FINITE operands overflowed to +-Inf (the result is +-Inf / NaN
-// as in IEEE arithmetic although the exact sum may be finite).
+// tests/test.exdot.gpu.cpp:24-46).  PUNDER = some product of two non-zero operands is below 2^-968 in magnitude (it has
+// bits below 2^-1074); POVER = a product of two FINITE operands is 2^1024 or more (it overflowed to +-Inf as a double).
 constexpr unsigned FLAG_PUNDER = 8u, FLAG_POVER = 16u, FLAG_NONFINITE = 7u;
-// PLOW_EXACT (set by the finalize kernel of a single-device reduction, together with PUNDER): the products flagged by
-// PUNDER did NOT lose anything -- each was formed exactly at a scaled exponent and accumulated in the LOW accumulator
-// (same 68-limb geometry, unit 2^-(1074 + LOW_SHIFT_BITS)), which the finalize folded back: its part at or above 2^-1074
-// exactly, the rest as the half / sticky bits of the rounding.  The result is then the correctly rounded exact dot product.
-constexpr unsigned FLAG_PLOW_EXACT = 32u;
-constexpr int LOW_SHIFT_DIGITS = 38, LOW_SHIFT_BITS = 32 * LOW_SHIFT_DIGITS;   // 1216: a b 2^1216 is normal for every a b >= 2^-2148
-// per accumulator slot: one 64-byte line for the flag word, then the low accumulator (SET_WORDS int64: 68 limbs + pad)
-constexpr int FLAG_BLOCK_BYTES = 64 + 72 * 8;
+// PLOW_EXACT / PHIGH_EXACT (set by the finalize kernel together with PUNDER / POVER): the flagged products did NOT lose
+// anything -- each was formed exactly at a scaled exponent and accumulated in the LOW / HIGH accumulator (the 68-limb
+// geometry of the main one, unit 2^-(1074 + EXT_SHIFT_BITS) resp. 2^(-1074 + EXT_SHIFT_BITS)), which the finalize folded
+// back: the high one exactly (a sum that is still beyond the double range after every cancellation yields +-Inf, as
+// rounding the exact value does), the low one exactly at or above 2^-1074 and as the half / sticky bits of the rounding
+// below.  The result is then the correctly rounded exact dot product -- what mpfr at 4196 bits returns.
+constexpr unsigned FLAG_PLOW_EXACT = 32u, FLAG_PHIGH_EXACT = 64u;
+// 1216 bits: a b 2^1216 is normal for every a b >= 2^-2148, a b 2^-1216 for every a b in [2^1024, 2^2048)
+constexpr int EXT_SHIFT_DIGITS = 38, EXT_SHIFT_BITS = 32 * EXT_SHIFT_DIGITS;
+constexpr int LOW_SHIFT_DIGITS = EXT_SHIFT_DIGITS, LOW_SHIFT_BITS = EXT_SHIFT_BITS;
+constexpr int EXT_WORDS = 2 * SET_WORDS;   // an exported extension: [low digit set | high digit set]
+// per accumulator slot: one 64-byte line for the flag word, then the low and the high accumulator (SET_WORDS int64 each:
+// 68 limbs + pad)
+constexpr int FLAG_BLOCK_BYTES = 64 + EXT_WORDS * 8;
 __device__ __forceinline__ long long *low_acc_of(unsigned *gflags) { return (long long *)((char *)gflags + 64); }
+__device__ __forceinline__ long long *high_acc_of(unsigned *gflags) { return low_acc_of(gflags) + SET_WORDS; }
 
 // ---------------------------------------------------------------------------------------------
 // error-free transforms (ExSUM.FPE.cl:27-32 KnuthTwoSum; ExDOT.Superacc.cl:25-29 TwoProductFMA)
@@ -119,15 +124,37 @@ __device__ __forceinline__ void lds_add(long long *col, double x, unsigned &flag
 // final step, run by ONE thread on NL limbs held in LDS/local memory
 // ---------------------------------------------------------------------------------------------
 // carry-propagate: digits 0..NL-2 end in [0,2^32), the top limb keeps the signed remainder
-__device__ inline void normalize_digits(long long *v)
+__device__ inline void normalize_digits(long long *v, int nd = NL)
 {
     long long carry = 0;
-    for (int i = 0; i < NL - 1; ++i) {
+    for (int i = 0; i < nd - 1; ++i) {
         long long t = v[i] + carry;
         carry = t >> 32;  // arithmetic
         v[i] = t & 0xffffffffll;
     }
-    v[NL - 1] += carry;
+    v[nd - 1] += carry;
+}
+
+// main digits v[NL] (any signed words) + high digits h[NL] at EXT_SHIFT_DIGITS digits up, exactly.  Returns 0 and leaves
+// the normalised sum in v when it fits the main geometry (|sum| < 2^(32 NL - 1) units, far above the double range), else
+// +1 / -1 = the sign of a sum that is out of range whatever the rounding.  c: NL + EXT_SHIFT_DIGITS words of scratch.
+__device__ inline int fold_high_digits(long long *v, const long long *h, long long *c)
+{
+    constexpr int ND = NL + EXT_SHIFT_DIGITS;
+    for (int i = 0; i < ND; ++i) c[i] = (i < NL ? v[i] : 0) + (i >= EXT_SHIFT_DIGITS ? h[i - EXT_SHIFT_DIGITS] : 0);
+    normalize_digits(c, ND);
+    bool zeros = c[ND - 1] == 0, ones = c[ND - 1] == -1;
+    for (int i = NL; i < ND - 1; ++i) {
+        zeros = zeros && c[i] == 0;
+        ones = ones && c[i] == 0xffffffffll;
+    }
+    // (a negative value whose digit NL-1 has its top bit clear does not fit either: the signed top digit must hold it)
+    if (ones && !((c[NL - 1] >> 31) & 1)) ones = false;
+    if (zeros && ((c[NL - 1] >> 31) & 1)) zeros = false;
+    if (!zeros && !ones) return c[ND - 1] < 0 ? -1 : 1;
+    for (int i = 0; i < NL - 1; ++i) v[i] = c[i];
+    v[NL - 1] = zeros ? c[NL - 1] : c[NL - 1] - 0x100000000ll;
+    return 0;
 }
 
 // correctly rounded (RN-even) double of the normalised digits; returns the bit pattern

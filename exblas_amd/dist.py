@@ -3,7 +3,7 @@
 The reference's distributed path is one ``MPI_Reduce`` of the 41 normalised limbs (MPI_LONG, MPI_SUM) followed by
 ``Round`` on the root, inside the library call (src/cpu/blas/blas1/ExSUM.cpp:142-152, :266-273; scatter :33-63).
 Here every rank (one process per GPU) reduces its shard to a normalised digit set that stays in HBM (72 int64 =
-576 B; plus the low digit set of the same size, all zero unless ExDOT products underflowed), ``ncclAllReduce(ncclInt64, ncclSum)`` -- called from C++ on the caller's stream, RCCL over xGMI -- adds them,
+576 B; plus the low and high digit sets of the same size, all zero unless ExDOT products left the double range), ``ncclAllReduce(ncclInt64, ncclSum)`` -- called from C++ on the caller's stream, RCCL over xGMI -- adds them,
 and every rank runs the same carry-propagation + rounding kernel.  ExGEMV / ExGEMM shard the outputs: x resp. B is
 broadcast, y resp. C all-gathered (``exblas_exgemv_sharded_dev`` / ``exblas_exgemm_sharded_dev``).
 

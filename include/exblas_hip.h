@@ -55,21 +55,27 @@ extern "C" {
 #define EXBLAS_OUT_FLAGS 2    /* bit0 +inf, bit1 -inf, bit2 NaN seen in the input.  ExDOT also:
                                * bit3 (PRODUCT_UNDERFLOW) = a product of two non-zero operands was below 2^-968, i.e. had bits
                                *   below 2^-1074, the last place of the double-range accumulator;
-                               * bit5 (PRODUCT_LOW_EXACT), set with bit3 = those products lost nothing: each was formed again
-                               *   at a scaled exponent (error-free) and summed in a second, LOW accumulator that the finalize
-                               *   kernel folded back (its part below 2^-1074 as the half / sticky bits of the rounding) -- the
-                               *   result is the correctly rounded EXACT dot product.  The library's multi-rank calls all-reduce
-                               *   the low digit set beside the main one, so this holds for every rank count.  Bit3 WITHOUT bit5
-                               *   only arises where low sets were not available -- exblas_finalize_dev on user-held digit sets,
-                               *   a host-pointer exdot spread over several devices -- and means: the correctly rounded sum of
-                               *   the parts' values, each truncated at 2^-1074;
-                               * bit4 (PRODUCT_OVERFLOW) = a product of two FINITE operands overflowed: the result is +-Inf / NaN
-                               *   as in IEEE arithmetic although the exact sum may be finite.
-                               * No bit, or bits 3 + 5: the result is the MPFR-4196 value of tests/test.exdot.gpu.cpp:24-46.
-                               * The reference's kernels have both limits, silently. */
+                               * bit4 (PRODUCT_OVERFLOW) = a product of two FINITE operands was 2^1024 or more (+-Inf as a double);
+                               * bit5 (PRODUCT_LOW_EXACT, with bit3) / bit6 (PRODUCT_HIGH_EXACT, with bit4) = those products lost
+                               *   nothing: each was formed again at a scaled exponent (error-free) and summed in a second (LOW)
+                               *   resp. third (HIGH) accumulator that the finalize kernel folded back -- the high one exactly,
+                               *   1216 bits up; the low one exactly where it reaches 2^-1074 and as the half / sticky bits of
+                               *   the rounding below -- so the result is the correctly rounded EXACT dot product: finite where
+                               *   overflowing products cancel (IEEE arithmetic and the reference's kernels give Inf - Inf =
+                               *   NaN there), +-Inf where the exact sum is beyond the double range (if it is also beyond the
+                               *   record's digits, 2^1101, bit0 / bit1 is set as for an infinity in the input and the digit
+                               *   fields are meaningless).  The library's multi-rank calls all-reduce the low and high digit
+                               *   sets beside the main one, so this holds for every rank count.  Bit3 / bit4 WITHOUT bit5 /
+                               *   bit6 only arises where those sets were not available -- exblas_finalize_dev on user-held
+                               *   digit sets, a host-pointer exdot spread over several devices -- and means: the correctly
+                               *   rounded sum of the parts' values, each part truncated at 2^-1074 resp. saturated to +-Inf.
+                               * Whatever the bits (3..6), a result of a single call or of the library's multi-rank calls is
+                               * the MPFR-4196 value of tests/test.exdot.gpu.cpp:24-46.  The reference's kernels have both
+                               * limits, silently. */
 #define EXBLAS_FLAG_PRODUCT_UNDERFLOW 8
 #define EXBLAS_FLAG_PRODUCT_OVERFLOW 16
 #define EXBLAS_FLAG_PRODUCT_LOW_EXACT 32
+#define EXBLAS_FLAG_PRODUCT_HIGH_EXACT 64
 #define EXBLAS_OUT_CANON 4    /* 41 canonical limbs (52-bit, reference geometry) */
 #define EXBLAS_OUT_DIGITS 48  /* 68 normalised 32-bit digits, then 3 flag indicators + 1 pad word: */
 #define EXBLAS_SET_WORDS 72   /* words [48,120) = one "digit set", the int64-sum all-reduce payload */
@@ -246,8 +252,9 @@ int exblas_last_gemm_info_ctx(exblas_ctx_t *ctx, int *out8);
 /* ---- (2b) multi-GPU: one process per GPU ----------------------------------------------------- */
 /* The reference reduces across processes inside the library call: local reduction, MPI_Reduce(MPI_LONG, MPI_SUM) of
  * the normalised limbs, Round on the root (src/cpu/blas/blas1/ExSUM.cpp:142-152, :266-273; scatter :33-63).  Here:
- * local reduction on each GPU, ONE int64-sum all-reduce launch over the two 576-byte digit sets (main digits; low digits = ExDOT products below
- * 2^-968, all zero otherwise), the same carry-propagation +
+ * local reduction on each GPU, ONE int64-sum all-reduce launch over the 576-byte main digit set and the two extension sets
+ * of the same size (low / high digits = ExDOT products below 2^-968 / beyond the double range, all zero otherwise), the
+ * same carry-propagation +
  * rounding kernel on every rank.  Integer addition is order-free, so the result is bit-identical for any number of
  * ranks and any shard boundaries.  ExGEMV / ExGEMM shard the outputs (no reduction collective): x resp. B is
  * replicated by one broadcast, y resp. C completed by an all-gather that overlaps the remaining compute.

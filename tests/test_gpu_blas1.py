@@ -387,7 +387,7 @@ def test_blas1_randomized_soak(ex):
     assert r.returncode == 0 and "0 mismatches" in r.stdout, (r.stdout[-3000:], r.stderr[-2000:])
 
 
-FLAG_PUNDER, FLAG_POVER, FLAG_PLOW_EXACT = 8, 16, 32
+FLAG_PUNDER, FLAG_POVER, FLAG_PLOW_EXACT, FLAG_PHIGH_EXACT = 8, 16, 32, 64
 
 
 def test_exdot_product_domain(ex, oracle):
@@ -395,8 +395,8 @@ def test_exdot_product_domain(ex, oracle):
     limit of the reference's kernels (its test oracle sums exact products in 4196 bits for that reason,
     tests/test.exdot.gpu.cpp:24-46).  Here the LOW side is closed: products below 2^-968 are formed again at a scaled
     exponent (error-free) and accumulated in a second accumulator that the finalize folds back, so the result is the
-    MPFR-4196 value; the record says so (EXBLAS_OUT_FLAGS bit 3 + bit 5).  The HIGH side is fenced: a product of two
-    finite operands that overflows sets bit 4 and the result is +-Inf / NaN as IEEE arithmetic gives.  No bit set = the
+    MPFR-4196 value; the record says so (EXBLAS_OUT_FLAGS bit 3 + bit 5).  The HIGH side likewise (bit 4 + bit 6): products
+    of finite operands at or beyond 2^1024 go, scaled down, to a third accumulator.  No bit set = the
     exact domain of round 2: limbs equal to the oracle's, result == MPFR.  Families: products straddling 2^-968, products
     that underflow to zero, zeros (0 * x must not raise anything), overflow; every variant; vector / strided / odd-tail."""
     import torch
@@ -437,14 +437,15 @@ def test_exdot_product_domain(ex, oracle):
         b3[::5] = 0.0
         a3[3], b3[3] = 5e-324, 0.0
         assert run(a3, b3, fpe, ee).flags == 0
-        # (5) finite operands, overflowing product -> bit 4 and +Inf / -Inf as IEEE arithmetic gives
+        # (5) finite operands, overflowing product -> bits 4 + 6 and the correctly rounded exact value: here 2^1100 + ...,
+        # beyond the double range, i.e. +-Inf (MPFR agrees); see test_exdot_overflowing_products_are_summed_exactly
         a4, b4 = big.copy(), big[::-1].copy()
         a4[j], b4[j] = np.ldexp(1.0, 600), np.ldexp(1.0, 500)
-        rec = ex.read_record(ex.exdot_dev(torch.from_numpy(a4).cuda(), torch.from_numpy(b4).cuda(), fpe, ee))
-        assert rec.flags == (FLAG_POVER | 1) and rec.exact == np.inf, (fpe, ee, rec.flags, rec.exact)
+        rec = run(a4, b4, fpe, ee)
+        assert (rec.flags & ~3) == (FLAG_POVER | FLAG_PHIGH_EXACT) and rec.exact == np.inf, (fpe, ee, rec.flags, rec.exact)
         a4[j] = -a4[j]
-        rec = ex.read_record(ex.exdot_dev(torch.from_numpy(a4).cuda(), torch.from_numpy(b4).cuda(), fpe, ee))
-        assert rec.flags == (FLAG_POVER | 2) and rec.exact == -np.inf
+        rec = run(a4, b4, fpe, ee)
+        assert (rec.flags & ~3) == (FLAG_POVER | FLAG_PHIGH_EXACT) and rec.exact == -np.inf
         # a true Inf operand is NOT a product overflow
         a4[j], b4[j] = np.inf, 2.0
         rec = ex.read_record(ex.exdot_dev(torch.from_numpy(a4).cuda(), torch.from_numpy(b4).cuda(), fpe, ee))
@@ -510,6 +511,108 @@ def test_exdot_underflowing_products_are_summed_exactly(ex, oracle):
     a = np.concatenate([x, -x, ld(rng.uniform(1, 2, 500), np.full(500, -540))])
     b = np.concatenate([x[::-1], x[::-1], ld(rng.uniform(1, 2, 500) * rng.choice([-1.0, 1.0], 500), rng.integers(-560, -520, 500))])
     check(a, b, "cancellation")
+
+
+def test_exdot_overflowing_products_are_summed_exactly(ex, oracle):
+    """The high accumulator at work: products of FINITE operands at or beyond 2^1024 (+-Inf as doubles) are formed again
+    at a scaled exponent and summed exactly; the finalize adds them back 1216 bits up.  Where they cancel, the result is
+    the finite MPFR-4196 value (the reference's kernels, and IEEE arithmetic, give Inf - Inf = NaN); where they do not,
+    the exact sum is beyond the double range and rounds to +-Inf, as MPFR's does.  Every variant, vector / strided /
+    tail paths, together with underflowing products, and next to true Inf / NaN operands (which keep IEEE semantics)."""
+    import torch
+    rng = np.random.default_rng(13)
+    assert oracle.mpfr() is not None
+    EX = FLAG_POVER | FLAG_PHIGH_EXACT
+
+    def check(a, b, what, inca=1, flags=EX, variants=FPE_VARIANTS_DOT):
+        nn = (a.size + inca - 1) // inca
+        want = oracle.mpfr_exdot(a, b, inca=inca, incb=inca, n=nn)
+        for fpe, ee in variants:
+            rec = ex.read_record(ex.exdot_dev(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), fpe, ee, incx=inca,
+                                              incy=inca, n=nn))
+            assert same_double(rec.exact, want), (what, fpe, ee, rec.flags, rec.exact.hex(), float(want).hex())
+            if np.isfinite(want):
+                assert rec.flags == flags, (what, fpe, ee, rec.flags)
+            else:     # a sum beyond 2^1101 cannot be held by the record's digits: reported like an infinity in the input
+                assert (rec.flags & ~3) == flags, (what, fpe, ee, rec.flags)
+        return want
+
+    def ld(m, e):
+        return np.ldexp(np.asarray(m, dtype=np.float64), np.asarray(e))
+
+    # (a) exact cancellation of two overflowing products leaves the ordinary part
+    assert check(np.array([2.0 ** 600, -2.0 ** 600, 3.0]), np.array([2.0 ** 500, 2.0 ** 500, 5.0]), "cancel") == 15.0
+    # (b) near-cancellation: the difference of two products near 2^1030 is a finite double (2^978 scale)
+    x, y = 1.0 + 2.0 ** -30, 1.0 + 2.0 ** -22
+    w = check(np.array([x * 2.0 ** 520, -x * 2.0 ** 520, 1.0]), np.array([y * 2.0 ** 510, y * (1 + 2.0 ** -52) * 2.0 ** 510, 1.0]), "near")
+    assert np.isfinite(w) and w < -2.0 ** 970
+    # (c) sums that stay beyond the range: inside the accumulator's headroom (2^1024 .. 2^1101) and beyond it, both signs
+    for e1, e2 in ((512, 512), (530, 540), (600, 500), (1023, 1023), (1000, 100)):
+        for sg in (1.0, -1.0):
+            w = check(np.array([sg * 2.0 ** e1, 7.0]), np.array([2.0 ** e2, 9.0]), f"over {sg} {e1}+{e2}")
+            assert w == sg * np.inf
+    # the boundary: 2^1024 exactly overflows as a double (diverted), (2 - 2^-52) 2^1023 does not (ordinary path, exact)
+    check(np.array([2.0 ** 512, -2.0 ** 512]), np.array([2.0 ** 512, 2.0 ** 512 * (1 - 2.0 ** -53)]), "2^1024 - (2^1024 - 2^971)")
+    a = np.array([np.ldexp(2.0 - 2.0 ** -52, 511), -np.ldexp(2.0 - 2.0 ** -52, 511)])
+    b = np.array([np.ldexp(1.0, 512), np.ldexp(1.0, 512)])
+    assert check(a, b, "largest finite products", flags=0) == 0.0
+    # (d) many overflowing products with random signs that cancel in pairs, among ordinary and underflowing ones
+    for n, inca in ((4000, 1), (4001, 1), (999, 3), (20011, 2)):
+        m = n * inca
+        ea = rng.integers(400, 1023, m)
+        eb = np.clip(rng.integers(1024, 2040, m) - ea, -1000, 1023)
+        a = ld(rng.uniform(1, 2, m) * rng.choice([-1.0, 1.0], m), ea)
+        b = ld(rng.uniform(1, 2, m), eb)
+        half = (m // (2 * inca)) * inca
+        a[half:2 * half] = -a[:half]                # every product of the first half has its negative in the second
+        b[half:2 * half] = b[:half]
+        k = min(50, m - 2 * half)
+        if k > 0:
+            a[2 * half:2 * half + k] = rng.uniform(-4, 4, k)
+            b[2 * half:2 * half + k] = rng.uniform(-4, 4, k)
+        w = check(a, b, f"pairs n={n} inc={inca}", inca)
+        assert np.isfinite(w)
+        # ... the same with tiny products in the mix: all four product flags
+        a2, b2 = a.copy(), b.copy()
+        a2[::11 * inca] = ld(rng.uniform(1, 2, a2[::11 * inca].size), -600)
+        b2[::11 * inca] = ld(rng.uniform(1, 2, a2[::11 * inca].size), -520)
+        a2[half:2 * half] = -a2[:half]
+        b2[half:2 * half] = b2[:half]
+        check(a2, b2, f"pairs + tiny n={n} inc={inca}", inca, flags=EX | FLAG_PUNDER | FLAG_PLOW_EXACT)
+    # (e) partial cancellation: the surviving sum is a product-sized number that is still a double
+    n = 3000
+    xs = ld(rng.uniform(1, 2, n), rng.integers(500, 520, n))
+    ys = ld(rng.uniform(1, 2, n), rng.integers(520, 540, n))
+    a = np.concatenate([xs, -xs, [2.0 ** 500, 1.5]])
+    b = np.concatenate([ys, ys, [2.0 ** 500, 2.5]])           # + 2^1000 + 3.75
+    w = check(a, b, "partial")
+    assert w == 2.0 ** 1000
+    # (f) true Inf / NaN operands keep IEEE semantics next to overflowing products
+    a = np.array([2.0 ** 600, -2.0 ** 600, np.inf, 1.0])
+    b = np.array([2.0 ** 500, 2.0 ** 500, 2.0, 1.0])
+    for fpe, ee in FPE_VARIANTS_DOT:
+        rec = ex.read_record(ex.exdot_dev(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), fpe, ee))
+        assert rec.exact == np.inf and rec.flags == (EX | 1)
+    a[2] = np.nan
+    rec = ex.read_record(ex.exdot_dev(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), 8, True))
+    assert np.isnan(rec.exact) and rec.flags == (EX | 4)
+    # (g) a long vector: the accumulate / finish split, several launches into one reduction
+    n = (1 << 20) + 5
+    a = ld(rng.uniform(1, 2, n) * rng.choice([-1.0, 1.0], n), rng.integers(505, 525, n))
+    b = ld(rng.uniform(1, 2, n), rng.integers(505, 525, n))
+    a[n // 2:2 * (n // 2)] = -a[:n // 2]
+    b[n // 2:2 * (n // 2)] = b[:n // 2]
+    a[-1], b[-1] = 1.25, 3.0                                  # (n is odd: the unpaired last element)
+    want = oracle.mpfr_exdot(a, b)
+    ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    third = n // 3
+    for lo, hi in ((0, third), (third, 2 * third), (2 * third, n)):
+        ex.exdot_accumulate_dev(ta[lo:hi], tb[lo:hi], 8, True)
+    rec = ex.read_record(ex.finish_dev())
+    assert same_double(rec.exact, want) and rec.flags == EX and np.isfinite(want)
+    three, five = torch.tensor([3.0], dtype=torch.float64, device="cuda"), torch.tensor([5.0], dtype=torch.float64, device="cuda")
+    rec = ex.read_record(ex.exdot_dev(three, five, 8, True))                      # (the accumulators were left clean)
+    assert rec.exact == 15.0 and rec.flags == 0
 
 
 def test_exdot_flags_survive_the_digit_set(ex):

@@ -66,10 +66,24 @@ def _run_all(ex, torch, comm, rank, world):
         rec = ex.read_record(r)
         assert rec.flags == 8 | 32, rec.flags
         out[f"dot_under{fpe}"] = (rec.exact, rec.flags)
+    # products beyond the double range (HIGH accumulator), spread over the shards so that they cancel only ACROSS ranks
+    # (a rank alone would overflow), mixed with underflowing ones: the same 8 finite bytes, flag bits 3..6, for every rank count
+    xo, yo = xu.clone(), yu.clone()
+    q = (nu - nu // 2 - 6) // 2              # (the last six elements stay ordinary)
+    xo[nu // 2: nu // 2 + q] *= 2.0 ** 560
+    yo[nu // 2: nu // 2 + q] *= 2.0 ** 540
+    xo[nu // 2 + q: nu // 2 + 2 * q] = -xo[nu // 2: nu // 2 + q]
+    yo[nu // 2 + q: nu // 2 + 2 * q] = yo[nu // 2: nu // 2 + q]
+    for fpe, ee in ((8, True), (0, False), (4, False)):
+        r = ex.exdot_dev(xo, yo, fpe, ee) if comm is None else ex.exdot_allreduce(comm, xo[u0:u1], yo[u0:u1], fpe, ee)
+        rec = ex.read_record(r)
+        assert rec.flags == 8 | 16 | 32 | 64 and np.isfinite(rec.exact), (rec.flags, rec.exact)
+        out[f"dot_over{fpe}"] = (rec.exact, rec.flags)
     if comm is None:
         from oracle import pyoracle as O
         if O.mpfr() is not None:
             assert out["dot_under8"][0] == O.mpfr_exdot(xu.cpu().numpy(), yu.cpu().numpy())
+            assert out["dot_over8"][0] == O.mpfr_exdot(xo.cpu().numpy(), yo.cpu().numpy())
     r0, r1 = ex.row_block(M, rank, world)
     c0, c1 = ex.row_block(N, rank, world)
     for fpe, ee in ((8, True), (0, False), (4, False)):
