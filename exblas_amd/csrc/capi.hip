@@ -905,6 +905,8 @@ struct HostPart {
     long long i0 = 0, i1 = 0;
     int rc = 0;
     const char *what = "";
+    bool want_ext = false;          // exdot over several parts: export the low / high digit sets instead of folding them
+    std::vector<long long> ext;     // ... and bring them to the host (EXT_WORDS)
 };
 
 // one part of the vector(s) on one virtual device; leaves the part's record in the context's pinned h_record
@@ -935,10 +937,21 @@ static void host_reduce_part(HostPart &p, const double *a, long long inca, const
         p.what = "accumulate";
     }
     if (p.rc) return;
-    p.rc = finish_on(c, c.stream, (int64_t *)c.d_record);
+    long long *d_ext = nullptr;
+    if (p.want_ext) {
+        std::lock_guard<std::mutex> lk(c.mu);
+        d_ext = (long long *)stage_buf(c, 2, sizeof(long long) * EXT_WORDS);
+        p.rc = (int)finalize_groups(c, c.stream, c.d_record, d_ext);
+    } else {
+        p.rc = finish_on(c, c.stream, (int64_t *)c.d_record);
+    }
     p.what = "finish";
     if (p.rc) return;
     e = hipMemcpyAsync(c.h_record, c.d_record, sizeof(long long) * OUT_WORDS, hipMemcpyDeviceToHost, c.stream);
+    if (e == hipSuccess && d_ext) {
+        p.ext.resize(EXT_WORDS);
+        e = hipMemcpyAsync(p.ext.data(), d_ext, sizeof(long long) * EXT_WORDS, hipMemcpyDeviceToHost, c.stream);
+    }
     if (e == hipSuccess) e = hipStreamSynchronize(c.stream);
     if (e != hipSuccess) { p.rc = (int)e; p.what = "record copy"; }
 }
@@ -957,6 +970,7 @@ static int host_reduce(long long n, const double *a, long long inca, const doubl
         parts[v].layer = 1 + v;
         parts[v].i0 = (n * v) / nv;
         parts[v].i1 = (n * (v + 1)) / nv;
+        parts[v].want_ext = nv > 1 && b != nullptr;
     }
     if (nv == 1) {
         host_reduce_part(parts[0], a, inca, b, incb, fpe, early_exit);
@@ -976,14 +990,25 @@ static int host_reduce(long long n, const double *a, long long inca, const doubl
         long long *d_sets;
         {
             std::lock_guard<std::mutex> lk(c0.mu);
-            d_sets = (long long *)stage_buf(c0, 2, sizeof(long long) * SET_WORDS * nv);
+            d_sets = (long long *)stage_buf(c0, 2, sizeof(long long) * (SET_WORDS * nv + EXT_WORDS));
         }
         for (int v = 0; v < nv; ++v) {
             Ctx &cv = ctx(parts[v].dev, parts[v].layer);
             EXB_CHECK(hipMemcpyAsync(d_sets + (size_t)v * SET_WORDS, cv.h_record + OUT_DIGITS,
                                      sizeof(long long) * SET_WORDS, hipMemcpyHostToDevice, c0.stream));
         }
-        EXB_CHECK(finalize_sets(d_sets, nv, 0u, c0.stream, c0.d_record));
+        // exdot: the parts exported their low / high digit sets (products outside the double range, superacc.hip.h)
+        // instead of folding them; their sums are folded once, like the multi-rank path does after its all-reduce
+        long long *d_ext = nullptr;
+        std::vector<long long> ext_sum;
+        if (parts[0].want_ext) {
+            ext_sum.assign(EXT_WORDS, 0);
+            for (auto &p : parts)
+                for (int i = 0; i < EXT_WORDS; ++i) ext_sum[i] += p.ext[i];
+            d_ext = d_sets + (size_t)SET_WORDS * nv;
+            EXB_CHECK(hipMemcpyAsync(d_ext, ext_sum.data(), sizeof(long long) * EXT_WORDS, hipMemcpyHostToDevice, c0.stream));
+        }
+        EXB_CHECK(finalize_sets(d_sets, nv, 0u, c0.stream, c0.d_record, d_ext));
         EXB_CHECK(hipMemcpyAsync(c0.h_record, c0.d_record, sizeof(long long) * OUT_WORDS, hipMemcpyDeviceToHost,
                                  c0.stream));
         EXB_CHECK(hipStreamSynchronize(c0.stream));

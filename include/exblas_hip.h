@@ -65,10 +65,10 @@ extern "C" {
                                *   NaN there), +-Inf where the exact sum is beyond the double range (if it is also beyond the
                                *   record's digits, 2^1101, bit0 / bit1 is set as for an infinity in the input and the digit
                                *   fields are meaningless).  The library's multi-rank calls all-reduce the low and high digit
-                               *   sets beside the main one, so this holds for every rank count.  Bit3 / bit4 WITHOUT bit5 /
-                               *   bit6 only arises where those sets were not available -- exblas_finalize_dev on user-held
-                               *   digit sets, a host-pointer exdot spread over several devices -- and means: the correctly
-                               *   rounded sum of the parts' values, each part truncated at 2^-1074 resp. saturated to +-Inf.
+                               *   sets beside the main one (a host-pointer exdot spread over several devices adds them on the
+                               *   host), so this holds for every rank / device count.  Bit3 / bit4 WITHOUT bit5 / bit6 only
+                               *   arises from exblas_finalize_dev on user-held digit sets, which has no such sets, and means:
+                               *   the correctly rounded sum of the sets' values, each truncated at 2^-1074 resp. saturated.
                                * Whatever the bits (3..6), a result of a single call or of the library's multi-rank calls is
                                * the MPFR-4196 value of tests/test.exdot.gpu.cpp:24-46.  The reference's kernels have both
                                * limits, silently. */

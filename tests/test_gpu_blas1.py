@@ -368,6 +368,23 @@ def test_host_api_spreads_over_virtual_devices(ex, oracle):
             bad = a[:1000].copy()
             bad[17] = np.inf
             assert ex.exsum(1000, bad, 1, 0, 8, True) == np.inf          # the non-finite indicators travel with the digit sets
+        # products outside the double range, cancelling only ACROSS the parts: the parts export their low / high digit
+        # sets and the fold happens once -- the MPFR value and flag bits 3..6 whatever the device list
+        m = 40000
+        xo = oracle.gen("fpuniform_signed", m, 31, 40, 20)
+        yo = oracle.gen("fpuniform_signed", m, 32, 40, 20)
+        xo[:m // 4] *= 2.0 ** 560
+        yo[:m // 4] *= 2.0 ** 540
+        xo[3 * m // 4:] = -xo[:m // 4]
+        yo[3 * m // 4:] = yo[:m // 4]
+        xo[m // 4:m // 2] *= 2.0 ** -520
+        yo[m // 4:m // 2] *= 2.0 ** -500
+        want_o = oracle.mpfr_exdot(xo, yo)
+        assert np.isfinite(want_o)
+        for devs in ([0], [0, 0], [0, 0, 0], [0] * 8):
+            assert lib.exblas_set_host_devices(len(devs), (C.c_int * len(devs))(*devs)) == 0
+            got = ex.exdot_record(m, xo, 1, 0, yo, 1, 0, 8, True)
+            assert got.exact == want_o and got.flags == 8 | 16 | 32 | 64, (devs, got.exact, got.flags)
         assert lib.exblas_set_host_devices(1, (C.c_int * 1)(7)) != 0     # no such device on this box
     finally:
         lib.exblas_set_host_devices(0, None)
