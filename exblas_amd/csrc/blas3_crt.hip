@@ -214,9 +214,12 @@ __host__ __device__ __forceinline__ void crt_group_step(CrtAcc<NL> &a, double r0
 
 // minus kappa M, carry propagation (limbs to [0, 2^24), the top one keeps the sign), then the limbs packed into a
 // 320-bit two's-complement integer (compile-time shifts)
-template <int NL>
-__host__ __device__ __forceinline__ void crt_acc_finish(CrtAcc<NL> &a, const double (&Ml)[NL], unsigned long long (&w)[CRT_W32 / 2])
+// (W words of output: the kernels ask for just enough to hold 24 NL bits -- 3 words for 6 and 8 limbs -- so that the
+// rounding routine walks 3 words instead of 5; the host self-test checks all CRT_W32 / 2)
+template <int NL, int W = CRT_W32 / 2>
+__host__ __device__ __forceinline__ void crt_acc_finish(CrtAcc<NL> &a, const double (&Ml)[NL], unsigned long long (&w)[W])
 {
+    static_assert(64 * W >= 24 * NL, "the words must hold every limb");
     const double kappa = rint(a.phi);
     double carry = 0.0;
     long long li[NL];
@@ -231,12 +234,12 @@ __host__ __device__ __forceinline__ void crt_acc_finish(CrtAcc<NL> &a, const dou
         }
     }
 #pragma unroll
-    for (int k = 0; k < CRT_W32 / 2; ++k) w[k] = 0ull;
+    for (int k = 0; k < W; ++k) w[k] = 0ull;
 #pragma unroll
     for (int i = 0; i < NL - 1; ++i) {                            // non-negative 24-bit fields: plain ORs
         const int bit = 24 * i, k = bit >> 6, sh = bit & 63;
         w[k] |= (unsigned long long)li[i] << sh;
-        if (sh > 40 && k + 1 < CRT_W32 / 2) w[k + 1] |= (unsigned long long)li[i] >> (64 - sh);
+        if (sh > 40 && k + 1 < W) w[k + 1] |= (unsigned long long)li[i] >> (64 - sh);
     }
     {   // the signed top limb: sign-extended add at its (compile-time) position
         constexpr int bit = 24 * (NL - 1), k0 = bit >> 6, sh = bit & 63;
@@ -246,7 +249,7 @@ __host__ __device__ __forceinline__ void crt_acc_finish(CrtAcc<NL> &a, const dou
         const unsigned long long hi = sh ? (unsigned long long)(T >> (64 - sh)) : ext;
         unsigned long long c = 0;
 #pragma unroll
-        for (int k = 0; k < CRT_W32 / 2; ++k) {
+        for (int k = 0; k < W; ++k) {
             const unsigned long long v = (k < k0) ? 0ull : (k == k0 ? lo : (k == k0 + 1 ? hi : ext));
             const unsigned long long s1 = w[k] + v, c1 = s1 < v ? 1ull : 0ull;
             const unsigned long long s2 = s1 + c, c2 = s2 < c ? 1ull : 0ull;
@@ -374,46 +377,94 @@ __device__ __forceinline__ void crt_residues_body(const double *__restrict__ src
                                                   size_t plane_stride)
 {
     unsigned w[NW][16];
-    unsigned sgn[16];   // the element's sign, as the float sign bit
+    unsigned sgn[16];   // bits of +-2^23 with the element's sign (see the modulus loop)
+    // ALL 16 loads are issued before the first use, from addresses clamped into the matrix (an element outside it is
+    // zeroed afterwards), and the conversion below is branch-free: the first version loaded and converted element by
+    // element under `if (in range)` -- the compiler kept the structure, i.e. 16 dependent memory round trips per thread
+    // (global_load_dwordx2 + s_waitcnt vmcnt(0) sixteen times; 64 % of the wave time was spent waiting)
+    double xr[16];
+    const int vc = min(v, nvec - 1);
+    if (CONTIG && l0 + 16 <= len) {
+        const double *q = src + (long long)vc * ld + l0;   // (consecutive addresses: merged into wider loads)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) xr[e] = q[e];
+    } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int lc = min(l0 + e, len - 1);
+            xr[e] = CONTIG ? src[(long long)vc * ld + lc] : src[(long long)lc * ld + vc];
+        }
+    }
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-        const int l = l0 + e;
-        double x = 0.0;
-        if (v < nvec && l < len) x = scale * (CONTIG ? src[(long long)v * ld + l] : src[(long long)l * ld + v]);
-        const I128 X = to_fixed(fabs(x), u);
-        w[0][e] = (unsigned)X.lo;
-        if constexpr (NW > 1) w[1][e] = (unsigned)(X.lo >> 32);
-        if constexpr (NW > 2) w[2][e] = (unsigned)X.hi;
-        if constexpr (NW > 3) w[3][e] = (unsigned)((unsigned long long)X.hi >> 32);
-        sgn[e] = x < 0.0 ? 0x80000000u : 0u;
+        const double x = (v < nvec && l0 + e < len) ? scale * xr[e] : 0.0;
+        // |x| / 2^u as an integer of NW 32-bit words (gemm_fixed.hip.h: to_fixed, magnitude only, no branches):
+        // sh = the mantissa's shift, >= -52 (the bits shifted out below are zero by construction), < 32 NW - 52
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(x);
+        const int be = (int)((bits >> 52) & 0x7ffu);
+        const unsigned long long m = be ? ((bits & 0x000fffffffffffffull) | 0x0010000000000000ull) : 0ull;
+        const int sh = be - 1023 - 52 - u;
+        const unsigned long long down = m >> ((-sh) & 63), up = m << (sh & 63);
+        unsigned long long lo, hi = 0;
+        if constexpr (NW <= 2) {
+            lo = sh >= 0 ? up : down;
+        } else {
+            const unsigned long long carry = (sh & 63) ? m >> ((64 - sh) & 63) : 0ull;   // bits that cross into the high word
+            lo = sh >= 64 ? 0ull : (sh >= 0 ? up : down);
+            hi = sh >= 64 ? up : (sh > 0 ? carry : 0ull);
+        }
+        w[0][e] = (unsigned)lo;
+        if constexpr (NW > 1) w[1][e] = (unsigned)(lo >> 32);
+        if constexpr (NW > 2) w[2][e] = (unsigned)hi;
+        if constexpr (NW > 3) w[3][e] = (unsigned)(hi >> 32);
+        sgn[e] = ((unsigned)(bits >> 32) & 0x80000000u) | 0x4b000000u;
     }
+    // The modulus loop in packed fp32 (v_pk_add_f32 / v_pk_fma_f32: two elements per instruction).  With S = 2^23 and
+    // cf = +-S (the element's sign): F = bits(s | cf) = +-(S + s) exactly (s < 2^20), sf = F - cf = +-s;
+    // q = (fma(sf, 1/p, 1.5 S) - 1.5 S) = the integer nearest to sf / p (|sf / p| < 2^22: the sum lies where the spacing of
+    // the floats is 1, and |sf fl(1/p) - sf / p| < 2^-10); r' = fma(q, -p, sf + 1.5 S) = 1.5 S + r with the symmetric
+    // residue r = sf - q p, |r| <= (p - 1) / 2 for the odd moduli, <= 128 for p = 256 -- every step exact -- and the LOW
+    // BYTE of r' is r as an int8 (+128 wraps to -128 = 128 mod 256).  Per element and modulus: NW dot4 + 1 or + 2.5
+    // packed instructions + 0.75 byte permutes, where the scalar form (cvt, xor, mul, rndne, fma, cvt, pack) took 6.5.
+    typedef float f2_t __attribute__((ext_vector_type(2)));
+    const float MAGIC = 12582912.0f;   // 1.5 * 2^23
+    const f2_t mg = {MAGIC, MAGIC};
 #pragma unroll 1
     for (int t = 0; t < L; ++t) {
         const float pf = (float)g_crt.p[t], invp = g_crt.invp[t];
+        const f2_t invp2 = {invp, invp}, np2 = {-pf, -pf};
         unsigned c[NW];
 #pragma unroll
         for (int j = 0; j < NW; ++j) c[j] = g_crt.c8[t][j];
-        union { v4i_t v; signed char b[16]; } pk;
+        v4i_t pk;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            unsigned s = 0;
+        for (int e4 = 0; e4 < 4; ++e4) {
+            f2_t rr[2];
 #pragma unroll
-            for (int j = 0; j < NW; ++j) s = __builtin_amdgcn_udot4(w[j][e], c[j], s, false);
-            // symmetric residue in float: s < 2^20 and q p < 2^21 are exact floats, so r = s - rint(s / p) p is exact;
-            // |s invp - s / p| < 2^-11 puts r within p / 2 + 1/8 of zero: |r| <= (p - 1) / 2 for the odd moduli, <= 128
-            // for p = 256 (+128 wraps to -128 = 128 mod 256 in the int8 plane).  The sign of the element is applied to
-            // s (rint is odd).  Four instructions where the integer form (truncated quotient, 24-bit multiply, two
-            // fix-ups, centring, sign select) took eleven.
-            const float sf = __uint_as_float(__float_as_uint((float)s) ^ sgn[e]);
-            const float r = fmaf(-rintf(sf * invp), pf, sf);
-            pk.b[e] = (signed char)(int)r;
+            for (int h = 0; h < 2; ++h) {
+                const int e = 4 * e4 + 2 * h;
+                unsigned s0 = 0, s1 = 0;
+#pragma unroll
+                for (int j = 0; j < NW; ++j) {
+                    s0 = __builtin_amdgcn_udot4(w[j][e], c[j], s0, false);
+                    s1 = __builtin_amdgcn_udot4(w[j][e + 1], c[j], s1, false);
+                }
+                const f2_t F = {__uint_as_float(s0 | sgn[e]), __uint_as_float(s1 | sgn[e + 1])};
+                const f2_t C = {__uint_as_float(sgn[e]), __uint_as_float(sgn[e + 1])};
+                const f2_t sf = F - C;
+                const f2_t q = __builtin_elementwise_fma(sf, invp2, mg) - mg;
+                rr[h] = __builtin_elementwise_fma(q, np2, sf + mg);
+            }
+            const unsigned lo = __builtin_amdgcn_perm(__float_as_uint(rr[0].y), __float_as_uint(rr[0].x), 0x0c0c0400u);
+            const unsigned hi = __builtin_amdgcn_perm(__float_as_uint(rr[1].y), __float_as_uint(rr[1].x), 0x04000c0cu);
+            pk[e4] = (int)(lo | hi);
         }
-        *(v4i_t *)(tile + (size_t)t * plane_stride) = pk.v;
+        *(v4i_t *)(tile + (size_t)t * plane_stride) = pk;
     }
 }
 
 template <bool CONTIG>
-__global__ void __launch_bounds__(256) k_crt_residues(const double *__restrict__ src, long long ld, int nvec, int len,
+__global__ void __launch_bounds__(256, 4) k_crt_residues(const double *__restrict__ src, long long ld, int nvec, int len,
                                                       double scale, const int *__restrict__ E,
                                                       const int *__restrict__ info, int which,
                                                       signed char *__restrict__ planes, size_t plane_stride, int vt0)
@@ -421,7 +472,11 @@ __global__ void __launch_bounds__(256) k_crt_residues(const double *__restrict__
     if (info[INFO_PATH] != PATH_CRT) return;
     const int L = info[INFO_CRT_L], need = info[which ? INFO_CRT_NB : INFO_CRT_NA];
     // vt: tile index inside `planes` (a row chunk of A' starts at vector tile vt0; B: vt0 = 0)
-    const int kc = blockIdx.x, vt = blockIdx.y, KC = gridDim.x;
+    // CONTIG: a workgroup reads 512 contiguous bytes of 64 vectors and consecutive workgroups continue along them (kc
+    // fastest).  Strided (vectors = columns): it reads 512 contiguous bytes of 64 ROWS l, so the workgroups that run
+    // together must be neighbours in v (vt fastest: together they sweep whole rows) -- with kc fastest they touched 512
+    // bytes every 64 KiB
+    const int kc = CONTIG ? blockIdx.x : blockIdx.y, vt = CONTIG ? blockIdx.y : blockIdx.x, KC = CONTIG ? gridDim.x : gridDim.y;
     const int r = CONTIG ? (threadIdx.x >> 2) : (threadIdx.x & 63), seg = CONTIG ? (threadIdx.x & 3) : (threadIdx.x >> 6);
     const int v = (vt0 + vt) * I8_T + r, l0 = kc * I8_T + seg * 16;
     const int u = (v < nvec ? E[v] : 0) - need;
@@ -645,12 +700,13 @@ __device__ __forceinline__ void crt_finish_body(int L, int na, int nb, int g, in
     for (int o = 0; o < 4; ++o) {
         const int gi = 4 * g + o;
         if (gi < row1) {
-            unsigned long long w5[CRT_W32 / 2];
-            crt_acc_finish<NL>(acc[o], Ml, w5);
+            constexpr int W = (24 * NL + 63) / 64;   // 3 words for 6 and 8 limbs, 5 for 12
+            unsigned long long w5[W];
+            crt_acc_finish<NL, W>(acc[o], Ml, w5);
             const int u0 = EA[gi] - na + ebj;
-            const double s = round_mode ? wide_round_reference<CRT_W32 / 2>(w5, u0) : wide_round_sel<CRT_W32 / 2>(w5, u0);
+            const double s = round_mode ? wide_round_reference<W>(w5, u0) : wide_round_sel<W>(w5, u0);
             double *cij = c + (long long)gi * ldc + gj;
-            *cij = (beta == 0.0) ? s : beta * (*cij) + s;
+            *cij = (beta == 0.0) ? s : beta * (*cij) + s;   // (fetching EA / C ahead of the reconstruction: 83 -> 110 VGPRs, 0.82 -> 0.87 ms)
         }
     }
 }
@@ -755,7 +811,7 @@ hipError_t exgemm_crt_prepare(Ctx &c, char transa, char transb, int m, int n, in
 
     // B's residues once for all row chunks; A's per chunk (exgemm_crt_rows)
     if (!tb)
-        hipLaunchKernelGGL((k_crt_residues<false>), dim3(KC, gx), dim3(256), 0, st, b, (long long)ldb, n, k, 1.0, EB, info,
+        hipLaunchKernelGGL((k_crt_residues<false>), dim3(gx, KC), dim3(256), 0, st, b, (long long)ldb, n, k, 1.0, EB, info,
                            1, PB, plane_b, 0);
     else
         hipLaunchKernelGGL((k_crt_residues<true>), dim3(KC, gx), dim3(256), 0, st, b, (long long)ldb, n, k, 1.0, EB, info,
@@ -787,7 +843,7 @@ hipError_t exgemm_crt_rows(const I8Plan &p, int row0, int row1, hipStream_t st)
             hipLaunchKernelGGL((k_crt_residues<true>), dim3(p.KC, ty_cnt), dim3(256), 0, st, p.a, (long long)p.lda, p.m, p.k,
                                p.alpha, p.EA, p.info, 0, p.PA, p.plane_a, ty0);
         else
-            hipLaunchKernelGGL((k_crt_residues<false>), dim3(p.KC, ty_cnt), dim3(256), 0, st, p.a, (long long)p.lda, p.m,
+            hipLaunchKernelGGL((k_crt_residues<false>), dim3(ty_cnt, p.KC), dim3(256), 0, st, p.a, (long long)p.lda, p.m,
                                p.k, p.alpha, p.EA, p.info, 0, p.PA, p.plane_a, ty0);
         // A few moduli per launch.  The workgroups of an XCD share their A / B tile streams through its L2 only while
         // they run in step; they start in step at the beginning of a launch and drift apart afterwards: about 12 rounds
