@@ -21,7 +21,7 @@ for step in "$@"; do
     tests_full) run tests_full timeout -k 10 900 python -m pytest tests -m gpu -x -q ;;
     bench) run bench timeout -k 10 600 python bench.py --steps 10 --warmup 3 ;;
     prof) export TMPDIR=/tmp; R=$PWD; rm -rf gpurun_out/prof; (cd /tmp && run_in() { :; }); \
-          run prof timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof" -- python3 "$R/bench.py" --no-cpu-baseline ;;
+          run prof timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof" -- python3 "$R/bench.py" --no-cpu-baseline --no-host-api ;;
     pmc_fetch) export TMPDIR=/tmp; R=$PWD; rm -rf gpurun_out/pmc_fetch; \
           run pmc_fetch timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$R/gpurun_out/pmc_fetch" -- python3 "$R/bench.py" --steps 3 --warmup 1 --prewarm-ms 0 --no-cpu-baseline ;;
     pmc_write) export TMPDIR=/tmp; R=$PWD; rm -rf gpurun_out/pmc_write; \
