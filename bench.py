@@ -174,7 +174,13 @@ def timed_steps(ex, torch, dist, comm, op, buffers, fpe, ee, steps, warmup, worl
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     timed = [p for i, p in enumerate(ev) if not (i % stride and steps >= 2 * stride)]
-    kms = sum(a.elapsed_time(b) for a, b in timed) / max(len(timed), 1)
+    samples = sorted(a.elapsed_time(b) for a, b in timed)
+    kms = sum(samples) / max(len(samples), 1)
+    # min and median of the sampled launches beside the mean (the reference times its kernel as the minimum of 20 runs,
+    # gpu:ExSUM.cpp:149-185; SURVEY 8d asks for min and median): local to this rank, informational
+    timed_steps.last_samples = {"kernel_ms_min": samples[0] if samples else None,
+                                "kernel_ms_median": samples[len(samples) // 2] if samples else None,
+                                "kernel_samples": len(samples)}
     if state["last"] is not rec:
         rec.copy_(state["last"])
     return dt, kms
@@ -670,6 +676,7 @@ def main():
         roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                 "traffic": load_traffic(args.traffic_json, f"k_{op}") if n_local == (1 << 28) else None,
                 "kernel": f"k_{op}", "kernel_ms": kms, "elements_per_launch": n_local, "rotating_buffers": nrot}
+        roof.update(getattr(timed_steps, "last_samples", {}))
         if world > 1:
             roof["note"] = ("per GPU: the algorithmic bytes of the rank's shard / the slowest rank's mean kernel time; "
                             "traffic counters are collected at N = 1 only")
