@@ -619,7 +619,13 @@ static hipError_t launch_exsum(Ctx &c, const double *a, long long n, long long i
 template <int N, bool EE, int COPIES, int U, bool NT, bool PF, int WPS = 1, bool HALVES = false, int ZM = 0>
 static void run_exdot(Ctx &c, const double *a, const double *b, long long n, hipStream_t st)
 {
-    int grid = grid_for(c, n, (long long)BLOCK * 2 * U, c.bpc_dot);
+    // Workgroups per CU: 48 at n = 2^28 (placement probe, round 2), but a workgroup should stream about five tiles or
+    // more: at n = 2^25 -- a rank's shard of ONE 2^28 vector over 8 GPUs -- 48 per CU leave 1.3 tiles per workgroup
+    // (some stream two, most one: 108 us with the finalize), 12 per CU 5.3 (93 us); 2^26: 179 -> 174 us with 24
+    // (tools/tune_shard.py).  An explicit smaller setting (exblas_set_tuning / EXBLAS_BPC_DOT) is kept.
+    const long long tiles = n / ((long long)BLOCK * 2 * U);
+    const int bpc = (int)min((long long)c.bpc_dot, max(4ll, tiles / (5ll * c.num_cu)));
+    int grid = grid_for(c, n, (long long)BLOCK * 2 * U, bpc);
     // An ODD number of workgroups: a workgroup's successive tiles (grid tiles = grid x 16 KiB apart) then walk through
     // the 32 KiB period with which the two streams' addresses compete for HBM channels, whatever b - a is.  With the
     // even grid (32 x 256) the step time at n = 2^28 depended on the relative placement of the two vectors, 0.625 ms
