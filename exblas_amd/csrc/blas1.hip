@@ -71,8 +71,10 @@ __global__ void __launch_bounds__(BLOCK) k_exsum(const double *__restrict__ a, l
                                                  unsigned *__restrict__ gflags, int ngroups, int chunked)
 {
     __shared__ long long s_acc[WAVES * NL * COPIES];
-    for (int i = threadIdx.x; i < WAVES * NL * COPIES; i += BLOCK) s_acc[i] = 0;
-    __syncthreads();
+    auto zero_lds = [&]() {   // (after the first tile's loads are in flight, see k_exdot)
+        for (int i = threadIdx.x; i < WAVES * NL * COPIES; i += BLOCK) s_acc[i] = 0;
+        __syncthreads();
+    };
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     long long *col = s_acc + wave * NL * COPIES + (lane & (COPIES - 1));
     unsigned flags = 0;
@@ -90,6 +92,7 @@ __global__ void __launch_bounds__(BLOCK) k_exsum(const double *__restrict__ a, l
     Bypass bypass;
 
     if constexpr (!PF) {
+        zero_lds();
         for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
             const d2_t *p = v + t * TILE + threadIdx.x;
             d2_t r[U];
@@ -133,6 +136,7 @@ __global__ void __launch_bounds__(BLOCK) k_exsum(const double *__restrict__ a, l
                 fpe_absorb_adaptive<N, EE, 2 * U, LdsSink<COPIES>, ZM>(fpe, x, sinkm, bypass);
             };
             fill(t, r0);
+            zero_lds();
             for (;;) {
                 fill(t + tstride, r1);
                 absorb(r0);
@@ -143,6 +147,8 @@ __global__ void __launch_bounds__(BLOCK) k_exsum(const double *__restrict__ a, l
                 t += tstride;
                 if (t >= tend) break;
             }
+        } else {
+            zero_lds();
         }
     }
     // remainder vectors, grid-strided one double2 at a time
@@ -198,8 +204,12 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_exdot(const double *__restrict__
                                                  unsigned *__restrict__ gflags, int ngroups)
 {
     __shared__ long long s_acc[WAVES * NL * COPIES];
-    for (int i = threadIdx.x; i < WAVES * NL * COPIES; i += BLOCK) s_acc[i] = 0;
-    __syncthreads();
+    // (zeroed below, AFTER the first tile's loads are in flight: a microsecond of every workgroup's life, which counts
+    // for the short shards of a multi-GPU job -- 2^25 elements are 16 us of HBM time per stream)
+    auto zero_lds = [&]() {
+        for (int i = threadIdx.x; i < WAVES * NL * COPIES; i += BLOCK) s_acc[i] = 0;
+        __syncthreads();
+    };
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     long long *col = s_acc + wave * NL * COPIES + (lane & (COPIES - 1));
     unsigned flags = 0;
@@ -216,6 +226,7 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_exdot(const double *__restrict__
     constexpr long long TILE = (long long)BLOCK * U;
     const long long ntiles = nv / TILE;
     if constexpr (!PF) {
+        zero_lds();
         for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
             const long long base = t * TILE + threadIdx.x;
             d2_t ra[U], rb[U];
@@ -245,6 +256,7 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_exdot(const double *__restrict__
                 rb[u] = ld2<NT>(vb + base + u * BLOCK);
             }
         }
+        zero_lds();
         if constexpr (HALVES) {
             while (t < ntiles) {
                 const long long tn = t + gridDim.x;
