@@ -18,6 +18,7 @@
 #include "superacc.hip.h"
 #include "fpe.hip.h"
 #include "exblas_internal.h"
+#include <hip/hip_ext.h>
 
 namespace exb {
 
@@ -569,6 +570,20 @@ __global__ void __launch_bounds__(BLOCK) k_exsum_segmented(const double *__restr
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
+
+// streaming-kernel launch: plain, or -- when the context holds events for it -- with the events attached to the
+// dispatch packet itself (exblas_internal.h: launch_stop_event)
+#define EXB_LAUNCH_STREAMING(c, kernel, grid, st, ...)                                                                \
+    do {                                                                                                               \
+        if ((c).launch_stop_event || (c).launch_start_event) {                                                         \
+            hipEvent_t ev0_ = (c).launch_start_event, ev1_ = (c).launch_stop_event;                                    \
+            (c).launch_start_event = (c).launch_stop_event = nullptr;                                                  \
+            hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(BLOCK), 0, st, ev0_, ev1_, 0, __VA_ARGS__);                 \
+        } else {                                                                                                       \
+            hipLaunchKernelGGL(kernel, dim3(grid), dim3(BLOCK), 0, st, __VA_ARGS__);                                   \
+        }                                                                                                              \
+    } while (0)
+
 static inline int grid_for(const Ctx &c, long long work_items, long long per_block, int blocks_per_cu)
 {
     long long want = (work_items + per_block - 1) / per_block;
@@ -589,8 +604,8 @@ static void run_exsum(Ctx &c, const double *a, long long n, hipStream_t st)
     // an odd number of workgroups (one resident slot left idle): the tiles a workgroup has in flight are grid x 16 KiB
     // apart, and with an even grid they compete for the same HBM channels -- 865 against 855 Gelem/s at n = 2^28
     if (grid == c.num_cu * bpc && grid > 1 && !(grid & 1)) grid -= 1;
-    hipLaunchKernelGGL((k_exsum<N, EE, COPIES, U, NT, PF, ZM>), dim3(grid), dim3(BLOCK), 0, st, a, n, c.gacc, c.gflags,
-                       c.ngroups, c.variant == 9 ? 1 : 0);
+    EXB_LAUNCH_STREAMING(c, (k_exsum<N, EE, COPIES, U, NT, PF, ZM>), grid, st, a, n, c.gacc, c.gflags, c.ngroups,
+                         c.variant == 9 ? 1 : 0);
 }
 
 #ifndef EXBLAS_SUM_COPIES
@@ -622,8 +637,7 @@ static hipError_t launch_exsum(Ctx &c, const double *a, long long n, long long i
         }
     } else {
         int grid = grid_for(c, n, BLOCK, c.blocks_per_cu);
-        hipLaunchKernelGGL((k_exsum_strided<N, EE, COPIES>), dim3(grid), dim3(BLOCK), 0, st, a, n, inca, c.gacc,
-                           c.gflags, c.ngroups);
+        EXB_LAUNCH_STREAMING(c, (k_exsum_strided<N, EE, COPIES>), grid, st, a, n, inca, c.gacc, c.gflags, c.ngroups);
     }
     return hipGetLastError();
 }
@@ -644,8 +658,8 @@ static void run_exdot(Ctx &c, const double *a, const double *b, long long n, hip
     // (b - a = 16 KiB mod 32 KiB) to 0.667 ms (0 mod 32 KiB); odd: 0.625-0.635 ms for every placement
     // (tools/dot_align.py, profiles/r02_exdot_placement.log).
     if (grid > c.num_cu && !(grid & 1)) grid += 1;
-    hipLaunchKernelGGL((k_exdot<N, EE, COPIES, U, NT, PF, WPS, HALVES, ZM>), dim3(grid), dim3(BLOCK), 0, st, a, b, n, c.gacc,
-                       c.gflags, c.ngroups);
+    EXB_LAUNCH_STREAMING(c, (k_exdot<N, EE, COPIES, U, NT, PF, WPS, HALVES, ZM>), grid, st, a, b, n, c.gacc, c.gflags,
+                         c.ngroups);
 }
 
 template <int N, bool EE>
@@ -675,8 +689,8 @@ static hipError_t launch_exdot(Ctx &c, const double *a, long long inca, const do
         }
     } else {
         int grid = grid_for(c, n, BLOCK, c.blocks_per_cu);
-        hipLaunchKernelGGL((k_exdot_strided<N, EE, COPIES>), dim3(grid), dim3(BLOCK), 0, st, a, inca, b, incb, n,
-                           c.gacc, c.gflags, c.ngroups);
+        EXB_LAUNCH_STREAMING(c, (k_exdot_strided<N, EE, COPIES>), grid, st, a, inca, b, incb, n, c.gacc, c.gflags,
+                             c.ngroups);
     }
     return hipGetLastError();
 }

@@ -29,6 +29,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <chrono>
 #include <vector>
 
 namespace exb {
@@ -426,17 +427,58 @@ static int pipelined_step(exblas_comm_t *cm, const double *d_a, int64_t inca, co
         // ~3 us); the query is not legal while the stream is being captured -- there the dependency is always recorded
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         const bool capturing = hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
-        if (capturing || hipEventQuery(cm->ev_zero[slot]) != hipSuccess) e = hipStreamWaitEvent(st, cm->ev_zero[slot], 0);
-        (void)hipGetLastError();    // hipEventQuery's hipErrorNotReady is not an error
+        bool ready = false;
+        if (!capturing) {
+            // A host that submits faster than the GPU executes is always a few reductions ahead, so the event is "not
+            // ready" at submission time although it will be long before the kernel could start -- and the wait packet
+            // that would follow is a barrier in front of the streaming kernel (launch latency exposed, ~8 us per step
+            // on a 2^25-element shard).  The host waits instead, briefly and bounded: it then runs at most two
+            // reductions ahead of the device, which is all a two-slot pipeline can use.  EXBLAS_PIPE_SPIN_US=0: never.
+            static const long spin_us = [] { const char *v = getenv("EXBLAS_PIPE_SPIN_US"); return v ? atol(v) : 500l; }();
+            const auto t_start = std::chrono::steady_clock::now();
+            for (;;) {
+                if (hipEventQuery(cm->ev_zero[slot]) == hipSuccess) { ready = true; break; }
+                if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_start).count() >= spin_us) break;
+            }
+            (void)hipGetLastError();    // hipEventQuery's hipErrorNotReady is not an error
+        }
+        if (!ready) e = hipStreamWaitEvent(st, cm->ev_zero[slot], 0);
     }
     if (e != hipSuccess) return (int)e;
     if ((rc = exblas_set_accumulator_slot(slot)) != 0) return rc;
-    if (t0 && (e = hipEventRecord(t0, st)) != hipSuccess) return (int)e;
+    // The "kernel done" event the side stream waits for rides on the streaming kernel's own dispatch packet
+    // (hipExtLaunchKernelGGL, exblas_internal.h: launch_stop_event).  As a separate hipEventRecord it was a barrier packet
+    // between two streaming kernels, and the queue then exposed the launch latency of every kernel: in the kernel trace
+    // of a 2^25-element shard the next k_exsum started 13 us after the previous one ended, together with the side
+    // stream's first k_finalize (period 54 us around a 40.5 us kernel).  Not under stream capture (plain records there);
+    // EXBLAS_PIPE_EXT_EVENTS=0 restores the separate records (A/B).
+    static const bool ext_events = [] { const char *v = getenv("EXBLAS_PIPE_EXT_EVENTS"); return !(v && v[0] == '0'); }();
+    hipStreamCaptureStatus cs2 = hipStreamCaptureStatusNone;
+    const bool plain = !ext_events || (hipStreamIsCapturing(st, &cs2) == hipSuccess && cs2 != hipStreamCaptureStatusNone);
+    Ctx &cd = default_ctx();
+    if (plain) {
+        if (t0 && (e = hipEventRecord(t0, st)) != hipSuccess) return (int)e;
+    } else {
+        cd.launch_start_event = t0;
+        cd.launch_stop_event = t1 ? t1 : cm->ev_acc[slot];   // (a sampled step: the caller's pair brackets the kernel)
+    }
     rc = d_b ? exblas_exdot_accumulate_dev(d_a, inca, d_b, incb, n, fpe, early_exit, st)
              : exblas_exsum_accumulate_dev(d_a, n, inca, fpe, early_exit, st);
+    bool acc_recorded = false;
+    if (!plain) {
+        if (cd.launch_stop_event) {   // no kernel was launched (nothing to add, or a combination the reference ignores)
+            cd.launch_start_event = cd.launch_stop_event = nullptr;
+            if (!rc && t0) e = hipEventRecord(t0, st);
+            if (!rc && e == hipSuccess && t1) e = hipEventRecord(t1, st);
+        } else {
+            acc_recorded = !t1;
+        }
+    } else if (!rc && t1) {
+        e = hipEventRecord(t1, st);
+    }
     if (rc) return rc;
-    if (t1 && (e = hipEventRecord(t1, st)) != hipSuccess) return (int)e;
-    e = hipEventRecord(cm->ev_acc[slot], st);
+    if (e != hipSuccess) return (int)e;
+    if (!acc_recorded) e = hipEventRecord(cm->ev_acc[slot], st);
     if (e == hipSuccess) e = hipStreamWaitEvent(cm->side, cm->ev_acc[slot], 0);
     if (e != hipSuccess) return (int)e;
     // normalise the slot (leaves it zero), all-reduce main + low / high digit sets, carry-propagate + round: on the side stream
@@ -448,11 +490,13 @@ static int pipelined_step(exblas_comm_t *cm, const double *d_a, int64_t inca, co
         rc = (int)finalize_groups(c, cm->side, (long long *)d_out, ext);
     }
     if (rc) return rc;
-    if ((rc = comm_allreduce_sets(cm, (long long *)d_out + OUT_DIGITS, ext, cm->side)) != 0) return rc;
-    if ((rc = (int)finalize_sets((const long long *)d_out + OUT_DIGITS, 1, 0u, cm->side, (long long *)d_out, ext)) != 0) return rc;
+    // the slot's accumulators are zero again from here on (the exported sets of the slot are only touched by this side
+    // stream, in order): the event marks THIS point, not the end of the chain
     e = hipEventRecord(cm->ev_zero[slot], cm->side);
     cm->zero_pending[slot] = e == hipSuccess;
-    return (int)e;
+    if (e != hipSuccess) return (int)e;
+    if ((rc = comm_allreduce_sets(cm, (long long *)d_out + OUT_DIGITS, ext, cm->side)) != 0) return rc;
+    return (int)finalize_sets((const long long *)d_out + OUT_DIGITS, 1, 0u, cm->side, (long long *)d_out, ext);
 }
 
 int exblas_exsum_allreduce_pipelined_dev(exblas_comm_t *cm, const double *d_a_local, int64_t n_local, int64_t inca, int fpe,
@@ -476,11 +520,14 @@ int exblas_pipeline_drain_dev(exblas_comm_t *cm, void *stream)
     if (!cm) return (int)hipErrorInvalidValue;
     std::lock_guard<std::mutex> lk(cm->mu);
     hipError_t e = hipSuccess;
-    for (int s = 0; s < 2 && e == hipSuccess; ++s)
-        if (cm->zero_pending[s]) {
-            e = hipStreamWaitEvent((hipStream_t)stream, cm->ev_zero[s], 0);
-            cm->zero_pending[s] = false;
-        }
+    if (cm->zero_pending[0] || cm->zero_pending[1]) {
+        // join everything the side stream holds (ev_zero marks the middle of a chain -- the slot zero again --, not its end)
+        int rc0 = comm_side(cm);
+        if (rc0) return rc0;
+        e = hipEventRecord(cm->ev_done, cm->side);
+        if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)stream, cm->ev_done, 0);
+        cm->zero_pending[0] = cm->zero_pending[1] = false;
+    }
     cm->pipe_slot = 0;
     const int rc = exblas_set_accumulator_slot(0);
     return e != hipSuccess ? (int)e : rc;

@@ -22,6 +22,11 @@ struct Ctx {
     int ngroups = 32;        // EXBLAS_NGROUPS: global group accumulators the blocks add into
     int grid_adj = 0;        // EXBLAS_GRID_ADJ: workgroups added to the grid of the streaming ExSUM / ExDOT kernels
     int variant = 0;         // tuning variant of the production kernels (exblas_set_tuning)
+    // when set, the NEXT streaming ExSUM / ExDOT launch carries this event as the completion signal of its own dispatch
+    // packet (hipExtLaunchKernelGGL) and clears the field: no separate event packet follows the kernel in the queue
+    // (comm.hip: pipelined_step)
+    hipEvent_t launch_stop_event = nullptr;
+    hipEvent_t launch_start_event = nullptr;
     // which ExGEMM implementation the last call used.  The int8 path decides on the device: gemm_info_dev then points
     // at its info block (read lazily, with a synchronisation, by exblas_last_gemm_info); otherwise the host knows.
     int last_gemm_slices = 0;  // host-decided paths: 0 scalar kernel; 2..4: fp64-slice MFMA path with that many slices

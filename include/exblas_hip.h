@@ -302,10 +302,13 @@ int exblas_allreduce_finish_dev(exblas_comm_t *comm, void *stream, int64_t *d_ou
  * streaming kernel runs on `stream` into the accumulator slot the communicator alternates (0, 1, 0, ...); the second half
  * -- normalise, all-reduce, carry-propagate + round into d_out -- is enqueued on the communicator's own side stream behind
  * an event, so it overlaps the NEXT call's streaming kernel (a slot is reused only after its second half has left it
- * zero: the call makes `stream` wait for that).  d_out of call i is complete once work ordered after
+ * zero: the call waits for that -- on the HOST, for at most EXBLAS_PIPE_SPIN_US microseconds (default 500; the host
+ * then runs at most two reductions ahead of the device), after that by making `stream` wait; a wait packet in front of
+ * the streaming kernel would expose its launch latency on every call).  d_out of call i is complete once work ordered after
  * exblas_pipeline_drain_dev(comm, stream) runs (which also re-selects slot 0); use distinct d_out buffers for reductions
- * in flight (two).  ev_kernel_start / ev_kernel_end: optional hipEvent_t recorded on `stream` around the streaming kernel
- * (bench.py times the kernel with them), NULL otherwise.  Uses the device's default context: do not interleave with
+ * in flight (two).  ev_kernel_start / ev_kernel_end: optional hipEvent_t that bracket the streaming kernel (attached to
+ * its dispatch packet: they carry the kernel's own start / stop timestamps; bench.py times the kernel with them), NULL
+ * otherwise.  Uses the device's default context: do not interleave with
  * exblas_*_accumulate_dev / exblas_finish_dev on it before draining. */
 int exblas_exsum_allreduce_pipelined_dev(exblas_comm_t *comm, const double *d_a_local, int64_t n_local, int64_t inca,
                                          int fpe, int early_exit, void *stream, int64_t *d_out, void *ev_kernel_start,
