@@ -30,7 +30,7 @@ C_ABI_SYMBOLS = [
     "exblas_exgemv", "exblas_exgemm", "exblas_exsum_record", "exblas_exdot_record",
     "exblas_exsum_accumulate_dev", "exblas_exdot_accumulate_dev", "exblas_finish_dev", "exblas_set_tuning",
     "exblas_set_gemm_path", "exblas_last_gemm_slices", "exblas_exsum_segmented_dev",
-    "exblas_set_accumulator_slot", "exblas_stream_read2_dev", "exblas_extrsv_dev", "exblas_extrsv",
+    "exblas_set_accumulator_slot", "exblas_set_launch_events", "exblas_stream_read2_dev", "exblas_extrsv_dev", "exblas_extrsv",
     "exblas_extrsv_last_slow_rows", "exblas_reserve_workspace", "exblas_release_retired_workspaces", "exblas_release_workspace",
     "exblas_comm_unique_id", "exblas_comm_init_rccl", "exblas_comm_adopt_rccl", "exblas_comm_init_host",
     "exblas_comm_destroy", "exblas_comm_rank", "exblas_comm_size", "exblas_shard_range",
@@ -93,6 +93,7 @@ def load_library():
     L.exblas_set_round_mode.argtypes = [i32]
     L.exblas_set_tuning.argtypes = [i32, i32, i32]
     L.exblas_set_accumulator_slot.argtypes = [i32]
+    L.exblas_set_launch_events.argtypes = [vp, vp]
     L.exblas_set_gemm_path.argtypes = [i32]
     L.exblas_set_gemm_path.restype = None
     L.exblas_exsum_dev.argtypes = [vp, i64, i64, i32, i32, vp, vp]
@@ -255,6 +256,13 @@ def exdot_accumulate_dev(x, y, fpe=8, early_exit=True, incx=1, incy=1, n=None):
     _check(load_library().exblas_exdot_accumulate_dev(C.c_void_p(x.data_ptr()), incx, C.c_void_p(y.data_ptr()), incy,
                                                       n, fpe, int(early_exit), _stream_ptr(torch)),
            "exdot_accumulate_dev")
+
+
+def set_launch_events(ev_start, ev_stop):
+    """The next exsum / exdot accumulate call attaches these torch events (already recorded once, so that they own a
+    handle; either may be None) to its streaming kernel's dispatch packet: kernel start / stop timestamps, no packets."""
+    h = lambda e: C.c_void_p(e.cuda_event) if e is not None else None  # noqa: E731
+    _check(load_library().exblas_set_launch_events(h(ev_start), h(ev_stop)), "set_launch_events")
 
 
 def set_accumulator_slot(slot):

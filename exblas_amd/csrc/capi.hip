@@ -378,6 +378,15 @@ int exblas_set_accumulator_slot(int slot)
     return 0;
 }
 
+int exblas_set_launch_events(void *ev_start, void *ev_stop)
+{
+    Ctx &c = ctx(-1);
+    std::lock_guard<std::mutex> lk(c.mu);
+    c.launch_start_event = (hipEvent_t)ev_start;
+    c.launch_stop_event = (hipEvent_t)ev_stop;
+    return 0;
+}
+
 // out[0] = implementation of the most recent exgemm on this device (0 scalar kernel, 1 fp64 slices on MFMA-F64,
 // 2 int8 slices on the int8 matrix cores), out[1] / out[2] = digits (slices) of A / B, out[3..7] reserved.
 // The int8 path decides on the device: this call then synchronises the device and reads the decision back.

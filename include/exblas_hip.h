@@ -176,6 +176,12 @@ int exblas_finish_dev(void *stream, int64_t *d_out);
  * exblas_finish_dev on a second stream (ordered by events), so that the finalize of reduction i overlaps the
  * streaming kernel of reduction i+1 (bench.py does).  Returns 0, or an error for a slot other than 0 / 1. */
 int exblas_set_accumulator_slot(int slot);
+/* Timing without packets of its own: the NEXT exblas_exsum_accumulate_dev / exblas_exdot_accumulate_dev on the current
+ * device's default context attaches these hipEvent_t (either may be NULL) to the dispatch packet of its streaming kernel
+ * (hipExtLaunchKernelGGL): they then carry the kernel's own start / stop timestamps -- what rocprofv3 reports for that
+ * dispatch -- and no hipEventRecord barrier sits in the queue around the kernel.  Consumed by that one launch; a call that
+ * launches nothing leaves them unrecorded and cleared.  bench.py's kernel_ms. */
+int exblas_set_launch_events(void *ev_start, void *ev_stop);
 /* Sum `nsets` digit sets (EXBLAS_SET_WORDS int64 each = words [48,120) of a record, e.g. the
  * all-reduced payloads of several GPUs), carry-propagate once and round: the "single global
  * carry-propagated normalise".  d_out may alias d_digit_sets - EXBLAS_OUT_DIGITS (in-place).

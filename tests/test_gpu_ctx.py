@@ -152,3 +152,36 @@ def test_handle_lifecycle(ex):
         c.destroy()
     finally:
         lib.exblas_set_gemm_path(0)
+
+
+def test_launch_events_bracket_the_streaming_kernel(ex):
+    """exblas_set_launch_events: the next accumulate call attaches the events to its kernel's dispatch packet -- they
+    complete with the kernel, measure a plausible duration, are consumed by ONE launch, and the result is unchanged."""
+    import torch
+    n = (1 << 24) + 3
+    x = ex.gen_dev("ill_cond", n, 3, 1e32)
+    y = ex.gen_dev("lognormal", n, 4, 0.0, 2.0)
+    want_s = ex.read_record(ex.exsum_dev(x, 8, True))
+    want_d = ex.read_record(ex.exdot_dev(x, y, 8, True))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); e1.record()                       # (a torch event gets its handle at its first record())
+    torch.cuda.synchronize()
+    for op in ("sum", "dot"):
+        ex.set_launch_events(e0, e1)
+        if op == "sum":
+            ex.exsum_accumulate_dev(x, 8, True)
+        else:
+            ex.exdot_accumulate_dev(x, y, 8, True)
+        got = ex.read_record(ex.finish_dev())
+        torch.cuda.synchronize()
+        want = want_s if op == "sum" else want_d
+        assert got.exact == want.exact and (got.canon == want.canon).all()
+        ms = e0.elapsed_time(e1)
+        bytes_ = n * (8 if op == "sum" else 16)
+        assert 0.0 < ms < 5.0 and bytes_ / (ms * 1e-3) < 8.5e12, (op, ms)      # a kernel time, below the HBM peak
+        # consumed: a second launch without events does not move them
+        t_before = e0.elapsed_time(e1)
+        ex.exsum_accumulate_dev(x, 8, True)
+        ex.finish_dev()
+        torch.cuda.synchronize()
+        assert e0.elapsed_time(e1) == t_before
