@@ -697,6 +697,8 @@ def main():
             probe_rot, probe_same = probe_read(ex, torch, bufs, op == "exdot", n_local)
             roof["measured_read_probe_GBs"] = probe_rot
             roof["frac_of_probe"] = ach / probe_rot
+            roof["probe_note"] = ("the probe is timed over 12 back-to-back launches (the ~1 % of inter-kernel gaps included), "
+                                  "kernel_ms is the dispatch's own duration: a ratio within 1 % of 1 means equal")
             if same_buffer:
                 roof["same_buffer"]["measured_read_probe_GBs"] = probe_same
         return bufs, dt, roof, result, n_total
